@@ -1,0 +1,164 @@
+// C ABI of libsrmi.so (see include/srmi.h): validation + kernel dispatch.  No allocation, no sync.
+#include <stdarg.h>
+
+#include "common.h"
+
+namespace srmi {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_check(hipError_t e, const char* what) {
+    if (e == hipSuccess) return SRMI_OK;
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return SRMI_EHIP;
+}
+
+int layout_convert(const void* src, void* dst, int N, int C, int H, int W, int sl, int sd, int dl, int dd,
+                   hipStream_t s);
+
+static bool is_dtype(int v) { return v == SRMI_F32 || v == SRMI_BF16; }
+static bool is_layout(int v) { return v == SRMI_NHWC || v == SRMI_NCHW; }
+
+int conv_geom(const srmi_conv_desc& d, ConvGeom* g) {
+    if (d.N < 0 || d.H < 0 || d.W < 0 || d.Cin <= 0 || d.Cout <= 0 || d.kh <= 0 || d.kw <= 0 || d.stride <= 0 ||
+        d.pad < 0) {
+        set_error("conv desc: bad dims N=%d H=%d W=%d Cin=%d Cout=%d k=%dx%d stride=%d pad=%d", d.N, d.H, d.W, d.Cin,
+                  d.Cout, d.kh, d.kw, d.stride, d.pad);
+        return SRMI_EINVAL;
+    }
+    if (!is_dtype(d.in_dtype) || !is_dtype(d.out_dtype) || !is_dtype(d.res_dtype) || !is_layout(d.in_layout) ||
+        !is_layout(d.out_layout)) {
+        set_error("conv desc: bad dtype/layout code");
+        return SRMI_EINVAL;
+    }
+    if (d.compute != SRMI_COMPUTE_F32 && d.compute != SRMI_COMPUTE_BF16) {
+        set_error("conv desc: bad compute code %d", d.compute);
+        return SRMI_EINVAL;
+    }
+    if (d.act < SRMI_ACT_NONE || d.act > SRMI_ACT_SIGMOID) {
+        set_error("conv desc: bad activation code %d", d.act);
+        return SRMI_EINVAL;
+    }
+    if (d.shuffle < 1 || d.Cout % (d.shuffle * d.shuffle) != 0) {
+        set_error("conv desc: Cout=%d not divisible by shuffle^2 (r=%d)", d.Cout, d.shuffle);
+        return SRMI_EINVAL;
+    }
+    if (d.shuffle_order != SRMI_SHUFFLE_CRD && d.shuffle_order != SRMI_SHUFFLE_DCR) {
+        set_error("conv desc: bad shuffle order %d", d.shuffle_order);
+        return SRMI_EINVAL;
+    }
+    const int He = d.H + 2 * d.pad - d.kh, We = d.W + 2 * d.pad - d.kw;
+    g->Ho = (d.N == 0 || d.H == 0 || d.W == 0 || He < 0) ? 0 : He / d.stride + 1;
+    g->Wo = (d.N == 0 || d.H == 0 || d.W == 0 || We < 0) ? 0 : We / d.stride + 1;
+    g->Cf = d.Cout / (d.shuffle * d.shuffle);
+    g->Hf = g->Ho * d.shuffle;
+    g->Wf = g->Wo * d.shuffle;
+    g->in_cs = d.in_cstride ? d.in_cstride : d.Cin;
+    g->out_cs = d.out_cstride ? d.out_cstride : g->Cf;
+    if (g->in_cs < d.Cin || d.out_coffset < 0 || g->out_cs < g->Cf + d.out_coffset) {
+        set_error("conv desc: channel slice out of range (in_cs=%d Cin=%d out_cs=%d Cf=%d off=%d)", g->in_cs, d.Cin,
+                  g->out_cs, g->Cf, d.out_coffset);
+        return SRMI_EINVAL;
+    }
+    if ((d.in_layout == SRMI_NCHW && d.in_cstride && d.in_cstride != d.Cin) ||
+        (d.out_layout == SRMI_NCHW && (d.out_coffset || (d.out_cstride && d.out_cstride != g->Cf)))) {
+        set_error("conv desc: channel slices need NHWC");
+        return SRMI_EINVAL;
+    }
+    return SRMI_OK;
+}
+
+int select_kernel(const srmi_conv_desc& d) {
+    if (c64_supported(d)) return K_C64_BF16;
+    return K_GENERIC_F32;
+}
+
+static int conv_fwd_one(const srmi_conv_args* a, hipStream_t s) {
+    if (!a) { set_error("conv: NULL args"); return SRMI_EINVAL; }
+    ConvGeom g;
+    int rc = conv_geom(a->d, &g);
+    if (rc) return rc;
+    if ((long long)a->d.N * g.Ho * g.Wo == 0) return SRMI_OK;  // empty batch / image: nothing to do
+    if (!a->x || !a->w || !a->scale || !a->shift || !a->y) {
+        set_error("conv: NULL x/w/scale/shift/y");
+        return SRMI_EINVAL;
+    }
+    if (a->d.act == SRMI_ACT_PRELU && !a->alpha) {
+        set_error("conv: PReLU needs alpha");
+        return SRMI_EINVAL;
+    }
+    switch (select_kernel(a->d)) {
+        case K_C64_BF16: return c64_launch(*a, g, s);
+        default: return generic_launch(*a, g, s);
+    }
+}
+
+}  // namespace srmi
+
+using namespace srmi;
+
+extern "C" {
+
+int srmi_version(void) { return SRMI_VERSION; }
+
+const char* srmi_last_error(void) { return g_err; }
+
+int srmi_conv2d_kernel_name(const srmi_conv_desc* d, char* buf, size_t buf_len) {
+    if (!d || !buf || buf_len == 0) { set_error("kernel_name: NULL argument"); return SRMI_EINVAL; }
+    ConvGeom g;
+    int rc = conv_geom(*d, &g);
+    if (rc) return rc;
+    const char* nm = select_kernel(*d) == K_C64_BF16 ? "c64_bf16" : "generic_f32";
+    snprintf(buf, buf_len, "%s", nm);
+    return SRMI_OK;
+}
+
+int srmi_conv2d_packed_weight_bytes(const srmi_conv_desc* d, size_t* bytes) {
+    if (!d || !bytes) { set_error("packed_weight_bytes: NULL argument"); return SRMI_EINVAL; }
+    ConvGeom g;
+    int rc = conv_geom(*d, &g);
+    if (rc) return rc;
+    *bytes = select_kernel(*d) == K_C64_BF16 ? c64_packed_bytes(*d) : generic_packed_bytes(*d);
+    return SRMI_OK;
+}
+
+int srmi_conv2d_pack_weights(const srmi_conv_desc* d, const float* w_oihw, void* w_packed, void* stream) {
+    if (!d || !w_oihw || !w_packed) { set_error("pack_weights: NULL argument"); return SRMI_EINVAL; }
+    ConvGeom g;
+    int rc = conv_geom(*d, &g);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    return select_kernel(*d) == K_C64_BF16 ? c64_pack(*d, w_oihw, w_packed, s) : generic_pack(*d, w_oihw, w_packed, s);
+}
+
+int srmi_conv2d_fwd(const srmi_conv_args* a, void* stream) { return conv_fwd_one(a, (hipStream_t)stream); }
+
+int srmi_conv2d_fwd_seq(const srmi_conv_args* a, int32_t n, void* stream) {
+    if (n < 0 || (n > 0 && !a)) { set_error("fwd_seq: bad arguments"); return SRMI_EINVAL; }
+    for (int32_t i = 0; i < n; ++i) {
+        int rc = conv_fwd_one(a + i, (hipStream_t)stream);
+        if (rc) return rc;
+    }
+    return SRMI_OK;
+}
+
+int srmi_layout_convert(const void* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t src_layout,
+                        int32_t src_dtype, int32_t dst_layout, int32_t dst_dtype, void* stream) {
+    if (N < 0 || C < 0 || H < 0 || W < 0 || !is_layout(src_layout) || !is_layout(dst_layout) || !is_dtype(src_dtype) ||
+        !is_dtype(dst_dtype)) {
+        set_error("layout_convert: bad arguments");
+        return SRMI_EINVAL;
+    }
+    if ((size_t)N * C * H * W == 0) return SRMI_OK;
+    if (!src || !dst) { set_error("layout_convert: NULL buffer"); return SRMI_EINVAL; }
+    return layout_convert(src, dst, N, C, H, W, src_layout, src_dtype, dst_layout, dst_dtype, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,68 @@
+// Shared host/device helpers for libsrmi (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/srmi.h"
+
+namespace srmi {
+
+typedef unsigned short bf16_t;  // raw bf16 bits
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float bf2f(bf16_t u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
+// round-to-nearest-even, NaN stays NaN (plain cast -> v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+__device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
+    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float apply_act(float v, int act, float param, float alpha) {
+    switch (act) {
+        case SRMI_ACT_PRELU: return v >= 0.f ? v : v * alpha;
+        case SRMI_ACT_LRELU: return v >= 0.f ? v : v * param;
+        case SRMI_ACT_RELU: return v > 0.f ? v : 0.f;
+        case SRMI_ACT_TANH: return tanhf(v);
+        case SRMI_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+        default: return v;
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------
+void set_error(const char* fmt, ...);
+int hip_check(hipError_t e, const char* what);
+
+struct ConvGeom {
+    int Ho, Wo;        // conv output spatial size
+    int Cf;            // final channels = Cout / r^2
+    int Hf, Wf;        // final spatial size = Ho*r, Wo*r
+    int in_cs, out_cs; // effective channel strides
+};
+int conv_geom(const srmi_conv_desc& d, ConvGeom* g);  // validates, fills g
+
+static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
+
+// kernel families (dispatch.cpp decides, the .hip files implement)
+enum Kernel { K_GENERIC_F32 = 0, K_C64_BF16 = 1 };
+int select_kernel(const srmi_conv_desc& d);
+
+// generic f32-MFMA kernel (conv_generic.hip)
+size_t generic_packed_bytes(const srmi_conv_desc& d);
+int generic_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s);
+int generic_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s);
+
+// bf16 MFMA kernel for 3x3 / Cin=64 / Cout%64==0 (conv_c64_bf16.hip)
+bool c64_supported(const srmi_conv_desc& d);
+size_t c64_packed_bytes(const srmi_conv_desc& d);
+int c64_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s);
+int c64_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s);
+
+}  // namespace srmi

@@ -1,0 +1,201 @@
+// Generic fused conv2d on the exact-f32 MFMA (v_mfma_f32_32x32x2_f32), gfx950.
+//
+// Serves every shape the fast kernels do not: any kh x kw, stride, pad, Cin, Cout, NHWC/NCHW,
+// f32/bf16 storage, sub-pixel stores of any factor.  It is the <=1e-4 parity path
+// (SRMI_COMPUTE_F32): the f32 MFMA is bit-for-bit an fmaf chain, so results differ from the
+// reference's fp32 conv only by summation order.
+//
+// Mapping: implicit GEMM, M = N*Ho*Wo output pixels (flattened, so stride-2 and ragged shapes
+// need no special cases), N = Cout, K = kh*kw*Cin.  One wave owns a 32(M) x 32*NT(N) tile and
+// walks K straight from global memory (the activations of one tile are re-read from L1/L2 by
+// the taps; no LDS: this kernel is the fallback, not the roofline kernel).
+// K order inside a tap is permuted so each lane reads 4 consecutive channels (one 16-B load):
+// k-pair (c0+j, c0+4+j) is fed to MFMA j; A and B use the same permutation so the sum is the
+// same set of products.
+#include "common.h"
+
+namespace srmi {
+
+struct GenericParams {
+    const void* x; const float* w; const float* scale; const float* shift; const float* alpha;
+    const void* res; void* y;
+    int N, H, W, Cin, Cout, kh, kw, stride, pad;
+    int Ho, Wo, Cf, Hf, Wf, in_cs, out_cs, out_co;
+    int in_bf16, out_bf16, res_bf16, in_nchw, out_nchw, vec_ok;
+    int act; float act_param; int alpha_pc; int r; int dcr;
+    int Cin_pad, Cout_pad, M;
+};
+
+template <int NT>
+__global__ __launch_bounds__(256) void conv_generic_kernel(GenericParams p) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int m0 = (blockIdx.x * 4 + wave) * 32;
+    if (m0 >= p.M) return;  // wave-uniform; the kernel has no barriers
+    const int co0 = blockIdx.y * (32 * NT);
+
+    const int m = m0 + i;
+    const bool mvalid = m < p.M;
+    const int mm = mvalid ? m : 0;
+    const int ox = mm % p.Wo;
+    const int tq = mm / p.Wo;
+    const int oy = tq % p.Ho;
+    const int n = tq / p.Ho;
+
+    f32x16 acc[NT];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    const float* xf = (const float*)p.x;
+    const bf16_t* xb = (const bf16_t*)p.x;
+    const size_t HW = (size_t)p.H * p.W;
+
+    for (int ky = 0; ky < p.kh; ++ky) {
+        const int iy = oy * p.stride - p.pad + ky;
+        for (int kx = 0; kx < p.kw; ++kx) {
+            const int ix = ox * p.stride - p.pad + kx;
+            const bool v = mvalid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            const int tap = ky * p.kw + kx;
+            const float* wt = p.w + (size_t)tap * p.Cin_pad * p.Cout_pad + co0 + i;
+            const size_t pix = v ? (((size_t)n * p.H + iy) * p.W + ix) : 0;
+            for (int c0 = 0; c0 < p.Cin_pad; c0 += 8) {
+                const int cb = c0 + 4 * h;
+                float a[4] = {0.f, 0.f, 0.f, 0.f};
+                if (v) {
+                    if (p.vec_ok) {  // NHWC, Cin % 8 == 0, 16-B aligned rows
+                        if (p.in_bf16) {
+                            const u16x4 q = *(const u16x4*)(xb + pix * p.in_cs + cb);
+                            a[0] = bf2f(q[0]); a[1] = bf2f(q[1]); a[2] = bf2f(q[2]); a[3] = bf2f(q[3]);
+                        } else {
+                            const f32x4 q = *(const f32x4*)(xf + pix * p.in_cs + cb);
+                            a[0] = q[0]; a[1] = q[1]; a[2] = q[2]; a[3] = q[3];
+                        }
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int c = cb + j;
+                            if (c < p.Cin) {
+                                const size_t idx = p.in_nchw
+                                    ? ((size_t)n * p.Cin + c) * HW + (size_t)iy * p.W + ix
+                                    : pix * p.in_cs + c;
+                                a[j] = p.in_bf16 ? bf2f(xb[idx]) : xf[idx];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float* wr = wt + (size_t)(cb + j) * p.Cout_pad;
+#pragma unroll
+                    for (int t = 0; t < NT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], wr[32 * t], acc[t], 0, 0, 0);
+                }
+            }
+        }
+    }
+
+    // ---- fused epilogue: scale/shift -> act -> +residual -> (sub-pixel) store ---------------
+    const int rr = p.r * p.r;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int co = co0 + 32 * t + i;
+        const bool cvalid = co < p.Cout;
+        const int coc = cvalid ? co : 0;
+        const float sc = p.scale[coc], sh = p.shift[coc];
+        const float al = (p.act == SRMI_ACT_PRELU) ? p.alpha[p.alpha_pc ? coc : 0] : 0.f;
+        int c = coc, si = 0, sj = 0;
+        if (p.r > 1) {
+            if (p.dcr) { c = coc % p.Cf; const int s = coc / p.Cf; si = s / p.r; sj = s % p.r; }
+            else { c = coc / rr; const int s = coc % rr; si = s / p.r; sj = s % p.r; }
+        }
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+            const int n_r = __shfl(n, row), oy_r = __shfl(oy, row), ox_r = __shfl(ox, row);
+            if (!cvalid || m0 + row >= p.M) continue;
+            const int Y = oy_r * p.r + si, X = ox_r * p.r + sj;
+            float val = apply_act(acc[t][e] * sc + sh, p.act, p.act_param, al);
+            size_t oidx, ridx;
+            if (p.out_nchw) {
+                oidx = (((size_t)n_r * p.Cf + c) * p.Hf + Y) * p.Wf + X;
+                ridx = oidx;
+            } else {
+                const size_t px = ((size_t)n_r * p.Hf + Y) * p.Wf + X;
+                oidx = px * p.out_cs + p.out_co + c;
+                ridx = px * p.Cf + c;
+            }
+            if (p.res) val += p.res_bf16 ? bf2f(((const bf16_t*)p.res)[ridx]) : ((const float*)p.res)[ridx];
+            if (p.out_bf16) ((bf16_t*)p.y)[oidx] = f2bf(val);
+            else ((float*)p.y)[oidx] = val;
+        }
+    }
+}
+
+// OIHW f32 -> [tap][Cin_pad][Cout_pad] f32, zero padded
+__global__ void generic_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin, int Cout,
+                                    int kh, int kw, int Cin_pad, int Cout_pad, size_t total) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int co = (int)(idx % Cout_pad);
+        const size_t t1 = idx / Cout_pad;
+        const int c = (int)(t1 % Cin_pad);
+        const int tap = (int)(t1 / Cin_pad);
+        float v = 0.f;
+        if (co < Cout && c < Cin) {
+            const int ky = tap / kw, kx = tap % kw;
+            v = w[(((size_t)co * Cin + c) * kh + ky) * kw + kx];
+        }
+        out[idx] = v;
+    }
+}
+
+size_t generic_packed_bytes(const srmi_conv_desc& d) {
+    return (size_t)d.kh * d.kw * round_up(d.Cin, 8) * round_up(d.Cout, 32) * sizeof(float);
+}
+
+int generic_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s) {
+    const int Cin_pad = round_up(d.Cin, 8), Cout_pad = round_up(d.Cout, 32);
+    const size_t total = (size_t)d.kh * d.kw * Cin_pad * Cout_pad;
+    const int block = 256;
+    size_t blocks = (total + block - 1) / block;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(generic_pack_kernel, dim3((unsigned)blocks), dim3(block), 0, s, w_oihw, (float*)w_packed,
+                       d.Cin, d.Cout, d.kh, d.kw, Cin_pad, Cout_pad, total);
+    return hip_check(hipGetLastError(), "generic_pack_kernel");
+}
+
+int generic_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
+    const srmi_conv_desc& d = a.d;
+    GenericParams p;
+    p.x = a.x; p.w = (const float*)a.w; p.scale = a.scale; p.shift = a.shift; p.alpha = a.alpha;
+    p.res = a.residual; p.y = a.y;
+    p.N = d.N; p.H = d.H; p.W = d.W; p.Cin = d.Cin; p.Cout = d.Cout; p.kh = d.kh; p.kw = d.kw;
+    p.stride = d.stride; p.pad = d.pad;
+    p.Ho = g.Ho; p.Wo = g.Wo; p.Cf = g.Cf; p.Hf = g.Hf; p.Wf = g.Wf;
+    p.in_cs = g.in_cs; p.out_cs = g.out_cs; p.out_co = d.out_coffset;
+    p.in_bf16 = d.in_dtype == SRMI_BF16; p.out_bf16 = d.out_dtype == SRMI_BF16;
+    p.res_bf16 = d.res_dtype == SRMI_BF16;
+    p.in_nchw = d.in_layout == SRMI_NCHW; p.out_nchw = d.out_layout == SRMI_NCHW;
+    const size_t esz = p.in_bf16 ? 2 : 4;
+    p.vec_ok = !p.in_nchw && d.Cin % 8 == 0 && (g.in_cs * esz) % 16 == 0 && ((uintptr_t)a.x % 16) == 0;
+    p.act = d.act; p.act_param = d.act_param; p.alpha_pc = d.alpha_per_channel;
+    p.r = d.shuffle; p.dcr = d.shuffle_order == SRMI_SHUFFLE_DCR;
+    p.Cin_pad = round_up(d.Cin, 8); p.Cout_pad = round_up(d.Cout, 32);
+    const long long M = (long long)d.N * g.Ho * g.Wo;
+    if (M > 0x7fffffffLL) { set_error("generic conv: N*Ho*Wo = %lld exceeds int32", M); return SRMI_EINVAL; }
+    p.M = (int)M;
+    if (p.M == 0) return SRMI_OK;
+    const unsigned gx = (unsigned)((p.M + 127) / 128);
+    if (d.Cout > 32) {
+        dim3 grid(gx, (unsigned)((d.Cout + 63) / 64));
+        hipLaunchKernelGGL(conv_generic_kernel<2>, grid, dim3(256), 0, s, p);
+    } else {
+        dim3 grid(gx, 1);
+        hipLaunchKernelGGL(conv_generic_kernel<1>, grid, dim3(256), 0, s, p);
+    }
+    return hip_check(hipGetLastError(), "conv_generic_kernel");
+}
+
+}  // namespace srmi

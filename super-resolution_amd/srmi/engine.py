@@ -1,0 +1,229 @@
+"""Inference plans: a whole network forward as ONE native call that enqueues every fused conv.
+
+A plan owns (a) the packed weights and folded scale/shift vectors of every layer, (b) the NHWC
+activation buffers sized for one input shape, and (c) a ctypes array of ``srmi_conv_args`` that
+``srmi_conv2d_fwd_seq`` walks from C++ - one FFI crossing per forward instead of one per layer.
+Plans are cached per (input shape, compute mode) and rebuilt when a parameter or buffer of the
+module changes (``load_state_dict``, ``.to()``, an optimizer step): the signature is the tuple of
+(data_ptr, version) of every tensor the plan folded.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import functional as Fn
+
+
+def _sig(module: nn.Module):
+    s = []
+    for t in list(module.parameters()) + list(module.buffers()):
+        s.append((t.data_ptr(), t._version))
+    return tuple(s)
+
+
+def conv_parts(block):
+    """Split a reference-style `conv` block (Sequential(_conv [, BN] [, act]), P/ops.py:18-31) into
+    (conv2d, bn or None, act module or None)."""
+    mods = list(block.body)
+    c2d = mods[0]
+    bn = None
+    act = None
+    for m in mods[1:]:
+        if isinstance(m, nn.BatchNorm2d):
+            bn = m
+        else:
+            act = m
+    return c2d, bn, act
+
+
+class _Seq:
+    """Builder for a conv sequence."""
+
+    def __init__(self, device, compute):
+        self.device = device
+        self.compute = compute
+        self.adt = L.BF16 if compute == L.COMPUTE_BF16 else L.F32   # activation storage dtype
+        self.tdt = Fn.torch_dtype(self.adt)
+        self.layers = []   # (desc, x, w, scale, shift, alpha, residual, y)
+        self.keep = []     # tensors that must stay alive
+        self.kernels = []
+
+    def buf(self, *shape, dtype=None):
+        t = torch.empty(shape, dtype=dtype or self.tdt, device=self.device)
+        self.keep.append(t)
+        return t
+
+    def add(self, block_or_parts, x, y, N, H, W, *, residual=None, shuffle=1, in_layout=L.NHWC, out_layout=L.NHWC,
+            in_dtype=None, out_dtype=None, weight=None, k=None, stride=None, cin=None, cout=None):
+        c2d, bn, act = block_or_parts if isinstance(block_or_parts, tuple) else conv_parts(block_or_parts)
+        if bn is not None and bn.training:
+            raise NotImplementedError("srmi: train-mode BatchNorm is not part of the inference plan")
+        w = c2d.weight if weight is None else weight
+        cout_ = w.shape[0] if cout is None else cout
+        cin_ = w.shape[1] if cin is None else cin
+        k_ = w.shape[2] if k is None else k
+        stride_ = (c2d.stride[0] if hasattr(c2d, "stride") else 1) if stride is None else stride
+        pad_ = c2d.padding[0] if hasattr(c2d, "padding") else 0
+        code, param, alpha, apc = Fn.act_of(act)
+        desc = Fn.make_desc(N, H, W, cin_, cout_, k_, stride=stride_, pad=pad_,
+                            in_dtype=self.adt if in_dtype is None else in_dtype,
+                            out_dtype=self.adt if out_dtype is None else out_dtype,
+                            res_dtype=self.adt, in_layout=in_layout, out_layout=out_layout,
+                            compute=self.compute, act=code, act_param=param, alpha_per_channel=apc,
+                            shuffle=shuffle)
+        wp = Fn.pack_weights(desc, w.reshape(cout_, cin_, k_, k_))
+        scale, shift = Fn.fold_bn(c2d.bias, bn, cout_, self.device)
+        if alpha is not None:
+            alpha = alpha.detach()
+            if alpha.dtype != torch.float32:
+                raise TypeError("PReLU weight must be float32")
+        self.keep += [wp, scale, shift]
+        self.layers.append((desc, x, wp, scale, shift, alpha, residual, y))
+        self.kernels.append(L.kernel_name(desc))
+        return y
+
+    def finish(self):
+        n = len(self.layers)
+        arr = (L.ConvArgs * n)()
+        for i, (desc, x, wp, scale, shift, alpha, residual, y) in enumerate(self.layers):
+            Fn.fill_args(arr[i], desc, x if x is not None else 0, wp, scale, shift, alpha, residual, y)
+        return arr, n
+
+
+class GeneratorPlan:
+    """`Generator.forward` (P/srgan_model.py:27-39) for one (N, H, W) as 37 fused conv launches."""
+
+    def __init__(self, gen, N, H, W, compute):
+        dev = next(gen.parameters()).device
+        s = _Seq(dev, compute)
+        self.N, self.H, self.W = N, H, W
+        nf = gen.conv01.body[0].out_channels
+        img = gen.conv01.body[0].in_channels
+        # conv01 reads the caller's NCHW f32 tensor directly (no separate re-layout pass)
+        skip = s.buf(N, H, W, nf)
+        s.add(gen.conv01, None, skip, N, H, W, in_layout=L.NCHW, in_dtype=L.F32)
+        cur = skip
+        tmp = s.buf(N, H, W, nf)
+        run = s.buf(N, H, W, nf)
+        for blk in gen.body:                       # ResBlock, P/ops.py:45-48
+            s.add(blk.body[0], cur, tmp, N, H, W)
+            s.add(blk.body[1], tmp, run, N, H, W, residual=cur)   # in place on `run` after block 0
+            cur = run
+        feat = s.buf(N, H, W, nf)
+        s.add(gen.conv02, cur, feat, N, H, W, residual=skip)      # P/srgan_model.py:33-34
+        x, h, w = feat, H, W
+        for up in gen.tail:                        # Upsampler, P/ops.py:74-78
+            r = up.body[1].upscale_factor
+            c2d = up.body[0].body[0]
+            act = up.body[2] if len(up.body) > 2 else None
+            y = s.buf(N, h * r, w * r, c2d.out_channels // (r * r))
+            s.add((c2d, None, act), x, y, N, h, w, shuffle=r)
+            x, h, w = y, h * r, w * r
+        self.sr_shape = (N, img, h, w)
+        sr0 = torch.empty(self.sr_shape, dtype=torch.float32, device=dev)   # placeholder; run() allocates fresh outputs
+        s.add(gen.last_conv, x, sr0, N, h, w, out_layout=L.NCHW, out_dtype=L.F32)   # conv + tanh -> NCHW f32
+        self.feat_nhwc = feat
+        self.nf = nf
+        self.dev = dev
+        self.args, self.n = s.finish()
+        self.kernels = s.kernels
+        self._seq = s
+
+    def run(self, x):
+        x = x.contiguous()
+        if x.dtype != torch.float32:
+            x = x.float()
+        self._x = x
+        # outputs are fresh tensors per call (a drop-in must not alias the previous call's result)
+        sr = torch.empty(self.sr_shape, dtype=torch.float32, device=self.dev)
+        self.args[0].x = x.data_ptr()
+        self.args[self.n - 1].y = sr.data_ptr()
+        L.check(L.load().srmi_conv2d_fwd_seq(self.args, self.n, Fn.stream_ptr()))
+        feat = Fn.layout_convert(self.feat_nhwc, self.N, self.nf, self.H, self.W, L.NHWC, L.NCHW, torch.float32)
+        return sr, feat
+
+
+class DiscriminatorPlan:
+    """`Discriminator.forward` in eval mode (P/srgan_model.py:65-73): 8 convs + 2 Linear as 1x1 convs."""
+
+    def __init__(self, dis, N, H, W, compute):
+        dev = next(dis.parameters()).device
+        s = _Seq(dev, compute)
+        self.N = N
+        act = dis.act
+        blocks = [dis.conv01, dis.conv02]
+        for b in dis.body:
+            blocks += [b.body[0], b.body[1]]
+        x, h, w, first = None, H, W, True
+        for blk in blocks:
+            c2d = blk.body[0]
+            st = c2d.stride[0]
+            ho, wo = (h + 2 * c2d.padding[0] - c2d.kernel_size[0]) // st + 1, (w + 2 * c2d.padding[0] - c2d.kernel_size[0]) // st + 1
+            y = s.buf(N, ho, wo, c2d.out_channels)
+            if first:
+                s.add(blk, None, y, N, h, w, in_layout=L.NCHW, in_dtype=L.F32)
+                first = False
+            else:
+                s.add(blk, x, y, N, h, w)
+            x, h, w = y, ho, wo
+        cl = x.shape[-1]
+        lin1, lin2 = dis.tail[0], dis.tail[2]
+        if lin1.in_features != cl * h * w:
+            raise RuntimeError(f"Discriminator: input {H}x{W} does not match linear_size {lin1.in_features}")
+        # flatten is x.view(-1, C*H*W) on NCHW (P/srgan_model.py:70); our buffer is NHWC, so permute the
+        # Linear's columns (c,h,w) -> (h,w,c) once at pack time.
+        w1 = lin1.weight.detach().view(lin1.out_features, cl, h, w).permute(0, 2, 3, 1).reshape(lin1.out_features, -1)
+        y1 = s.buf(N, 1, 1, lin1.out_features)
+        s.add((lin1, None, act), x, y1, N, 1, 1, weight=w1.contiguous(), k=1, stride=1, cin=lin1.in_features,
+              cout=lin1.out_features)
+        self.prob_shape = (N, lin2.out_features)
+        self.dev = dev
+        prob0 = torch.empty(self.prob_shape, dtype=torch.float32, device=dev)
+        s.add((lin2, None, dis.tail[3]), y1, prob0, N, 1, 1, weight=lin2.weight.detach(), k=1, stride=1,
+              cin=lin2.in_features, cout=lin2.out_features, out_dtype=L.F32)
+        self.args, self.n = s.finish()
+        self.kernels = s.kernels
+        self._seq = s
+
+    def run(self, x):
+        x = x.contiguous()
+        if x.dtype != torch.float32:
+            x = x.float()
+        self._x = x
+        prob = torch.empty(self.prob_shape, dtype=torch.float32, device=self.dev)
+        self.args[0].x = x.data_ptr()
+        self.args[self.n - 1].y = prob.data_ptr()
+        L.check(L.load().srmi_conv2d_fwd_seq(self.args, self.n, Fn.stream_ptr()))
+        return prob
+
+
+class PlanCache:
+    def __init__(self, factory):
+        self.factory = factory
+        self.plans = {}
+
+    def get(self, module, N, H, W, compute):
+        key = (N, H, W, compute)
+        sig = _sig(module)
+        hit = self.plans.get(key)
+        if hit is not None and hit[0] == sig:
+            return hit[1]
+        if hit is None and len(self.plans) >= 8:   # bound the buffers held for stale shapes
+            self.plans.pop(next(iter(self.plans)))
+        plan = self.factory(module, N, H, W, compute)
+        self.plans[key] = (sig, plan)
+        return plan
+
+    def clear(self):
+        self.plans.clear()
+
+    # plans hold device buffers and ctypes pointers: never copied or pickled with the module
+    def __deepcopy__(self, memo):
+        return PlanCache(self.factory)
+
+    def __getstate__(self):
+        return {"factory": self.factory, "plans": {}}

@@ -1,0 +1,214 @@
+"""GPU: whole-network parity of the drop-in `Generator` / `Discriminator` against the golden vectors
+the REFERENCE produced (tests/golden, made by oracle/make_golden.py), and size-independent properties
+at the BASELINE configuration.
+
+Bars (BASELINE.json north_star): fp32 path max-abs <= 1e-4 on [0,1] pixels; bf16 path PSNR within
+0.05 dB of the fp32 reference (operating point: the reference's own logged quality, 26.48 dB,
+P/metrics.csv:5240)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import srgan_oracle as O
+from oracle import weights as W
+from srmi import ops
+from srmi.srgan_model import Discriminator, Generator
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+FULL = ["gen_b1_1x3x12x16.npz", "gen_b2_2x3x8x8.npz", "gen_b16_1x3x16x16.npz",
+        "gen_b1_scale2_1x3x9x7.npz", "gen_b1_scale3_1x3x6x5.npz"]
+PIX_TOL = 1e-4      # on [0,1] pixels  ==  2e-4 on the tanh range [-1,1]
+
+
+def _load(golden_dir, name):
+    return np.load(os.path.join(golden_dir, name), allow_pickle=False)
+
+
+def _make_gen(g, compute):
+    nb, scale = int(g["num_block"]), int(g["scale"])
+    gen = Generator(num_block=nb, scale=scale)
+    gen.load_state_dict(O.to_torch(W.generator_weights(seed=int(g["wseed"]), alpha=float(g["alpha"]),
+                                                       num_block=nb, scale=scale)), strict=True)
+    return gen.to(DEV).eval().set_compute(compute)
+
+
+def _psnr01(a, b):
+    """PSNR on [0,1] pixels of two tanh-range images."""
+    mse = float(((a.astype(np.float64) - b.astype(np.float64)) ** 2).mean()) / 4.0
+    return 10.0 * np.log10(1.0 / mse)
+
+
+@pytest.fixture(autouse=True)
+def _restore_shared_prelu():
+    yield
+    with torch.no_grad():
+        Generator.__init__.__defaults__[4].weight.fill_(0.25)
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_generator_fp32_matches_reference(golden_dir, name):
+    g = _load(golden_dir, name)
+    gen = _make_gen(g, "fp32")
+    with torch.no_grad():
+        sr, feat = gen(torch.from_numpy(g["x"]).to(DEV))
+    torch.cuda.synchronize()
+    assert set(gen._plans.get(gen, *g["x"].shape[:1], *g["x"].shape[2:], 0).kernels) == {"generic_f32"}
+    assert sr.shape == g["sr"].shape and feat.shape == g["feat"].shape
+    e_sr = np.abs(sr.cpu().numpy() - g["sr"]).max() / 2.0
+    e_feat = (np.abs(feat.cpu().numpy() - g["feat"]) / np.maximum(1.0, np.abs(g["feat"]))).max()
+    assert e_sr <= PIX_TOL, e_sr
+    assert e_feat <= 1e-4, e_feat
+
+
+@pytest.mark.parametrize("name", FULL[:3])
+def test_generator_bf16_psnr(golden_dir, name):
+    g = _load(golden_dir, name)
+    gen = _make_gen(g, "bf16")
+    with torch.no_grad():
+        sr, feat = gen(torch.from_numpy(g["x"]).to(DEV))
+    kern = gen._plans.get(gen, g["x"].shape[0], g["x"].shape[2], g["x"].shape[3], 1).kernels
+    assert kern.count("c64_bf16") == 2 * int(g["num_block"]) + 3          # body + conv02 + 2 upsamplers
+    sr = sr.cpu().numpy()
+    # synthetic ground truth at the reference's logged operating point (26.48 dB)
+    rng = np.random.Generator(np.random.PCG64(99))
+    sigma = 2.0 * 10.0 ** (-26.48 / 20.0)
+    gt = g["sr"] + rng.standard_normal(g["sr"].shape) * sigma
+    p_ref, p_bf = _psnr01(g["sr"], gt), _psnr01(sr, gt)
+    direct = _psnr01(sr, g["sr"])
+    print(f"{name}: PSNR(ref,gt)={p_ref:.3f} PSNR(bf16,gt)={p_bf:.3f} PSNR(bf16,ref)={direct:.2f} dB")
+    assert abs(p_ref - p_bf) <= 0.05
+    assert direct >= 40.0
+
+
+def test_block_modules_standalone(golden_dir):
+    """conv / ResBlock / Upsampler called on their own (NCHW in, NCHW out) against the reference taps."""
+    g = _load(golden_dir, "gen_b1_1x3x12x16.npz")
+    gen = _make_gen(g, "fp32")
+    x = torch.from_numpy(g["x"]).to(DEV)
+    with torch.no_grad():
+        c1 = gen.conv01(x)
+        b0 = gen.body[0](c1)
+        feat = gen.conv02(b0, _residual=c1)
+        u0 = gen.tail[0](feat)
+    assert np.abs(c1.cpu().numpy() - g["tap_conv01"]).max() <= 1e-4
+    assert np.abs(b0.cpu().numpy() - g["tap_block0"]).max() <= 1e-4
+    assert np.abs(feat.cpu().numpy() - g["feat"]).max() <= 1e-4
+    assert np.abs(u0.cpu().numpy() - g["tap_up0"]).max() <= 1e-4
+
+
+def test_cfg1_fp32_vs_reference_samples(golden_dir):
+    """BASELINE config 1 (16x3x96x96): strided samples and fp64 moments of the reference's output."""
+    g = _load(golden_dir, "gen_b16_cfg1_16x3x96x96.npz")
+    gen = _make_gen(g, "fp32")
+    x = torch.from_numpy(W.lr_input((16, 3, 96, 96), seed=int(g["xseed"]))).to(DEV)
+    with torch.no_grad():
+        sr, feat = gen(x)
+    st, fs = int(g["stride"]), int(g["feat_stride"])
+    assert np.abs(sr[:, :, ::st, ::st].cpu().numpy() - g["sr_sample"]).max() / 2.0 <= PIX_TOL
+    fe = np.abs(feat[:, :, ::fs, ::fs].cpu().numpy() - g["feat_sample"]) / np.maximum(1.0, np.abs(g["feat_sample"]))
+    assert fe.max() <= 1e-4
+    n = sr.numel()
+    assert abs(sr.double().sum().item() - float(g["sr_sum"])) / n <= 1e-6
+    assert abs((sr.double() ** 2).sum().item() - float(g["sr_sumsq"])) / n <= 1e-6
+    assert abs(sr.abs().max().item() - float(g["sr_absmax"])) <= 2e-4
+
+
+def test_cfg1_bf16_vs_reference_samples(golden_dir):
+    g = _load(golden_dir, "gen_b16_cfg1_16x3x96x96.npz")
+    gen = _make_gen(g, "bf16")
+    x = torch.from_numpy(W.lr_input((16, 3, 96, 96), seed=int(g["xseed"]))).to(DEV)
+    with torch.no_grad():
+        sr, _ = gen(x)
+    st = int(g["stride"])
+    sample = sr[:, :, ::st, ::st].cpu().numpy()
+    rng = np.random.Generator(np.random.PCG64(100))
+    gt = g["sr_sample"] + rng.standard_normal(sample.shape) * 2.0 * 10.0 ** (-26.48 / 20.0)
+    direct = _psnr01(sample, g["sr_sample"])
+    print(f"cfg1 bf16: PSNR(bf16,ref)={direct:.2f} dB; dPSNR={_psnr01(sample, gt) - _psnr01(g['sr_sample'], gt):+.4f}")
+    assert abs(_psnr01(sample, gt) - _psnr01(g["sr_sample"], gt)) <= 0.05
+    n = sr.numel()
+    assert abs(sr.double().sum().item() - float(g["sr_sum"])) / n <= 2e-3     # mean within bf16 noise
+
+
+@pytest.mark.parametrize("compute", ["fp32", "bf16"])
+def test_batch_items_are_independent(compute):
+    """Inference shards by batch item with no collective: item i alone == item i in a batch."""
+    gen = Generator(num_block=2)
+    gen.load_state_dict(O.to_torch(W.generator_weights(seed=4, num_block=2)))
+    gen = gen.to(DEV).eval().set_compute(compute)
+    x = torch.from_numpy(W.lr_input((3, 3, 20, 28), seed=21)).to(DEV)
+    with torch.no_grad():
+        sr, feat = gen(x)
+        sr1, feat1 = gen(x[1:2])
+    assert torch.equal(sr[1:2], sr1) and torch.equal(feat[1:2], feat1)
+
+
+def test_tile_with_halo_equals_whole_frame_interior():
+    """Tiled inference (BASELINE config 5): far from the tile border a tile's output equals the whole
+    frame's.  Receptive-field radius of a 2-block generator = 4 + 5 + 1 + 0.5 + 0.25 -> 11 LR pixels."""
+    gen = Generator(num_block=2)
+    gen.load_state_dict(O.to_torch(W.generator_weights(seed=4, num_block=2)))
+    gen = gen.to(DEV).eval()
+    x = torch.from_numpy(W.lr_input((1, 3, 48, 64), seed=22)).to(DEV)
+    with torch.no_grad():
+        whole, _ = gen(x)
+        tile, _ = gen(x[:, :, 8:40, 16:56].contiguous())
+    r = 11
+    a = whole[:, :, 4 * (8 + r):4 * (40 - r), 4 * (16 + r):4 * (56 - r)]
+    b = tile[:, :, 4 * r:4 * (32 - r), 4 * r:4 * (40 - r)]
+    assert (a - b).abs().max().item() <= 1e-5
+
+
+def test_outputs_do_not_alias_between_calls():
+    gen = Generator(num_block=1).to(DEV).eval()
+    x = torch.from_numpy(W.lr_input((1, 3, 8, 8), seed=2)).to(DEV)
+    with torch.no_grad():
+        a, fa = gen(x)
+        a0 = a.clone()
+        b, fb = gen(-x)
+    assert a.data_ptr() != b.data_ptr() and fa.data_ptr() != fb.data_ptr()
+    assert torch.equal(a, a0)
+
+
+def test_plan_follows_weight_updates():
+    gen = Generator(num_block=1).to(DEV).eval()
+    x = torch.from_numpy(W.lr_input((1, 3, 8, 8), seed=2)).to(DEV)
+    with torch.no_grad():
+        a, _ = gen(x)
+        gen.last_conv.body[0].weight.mul_(0.5)          # in-place update bumps the version counter
+        b, _ = gen(x)
+        sd = O.to_torch(W.generator_weights(seed=9, num_block=1))
+        gen.load_state_dict(sd)
+        c, _ = gen(x)
+        ref, _ = O.generator_forward(sd, x.cpu(), num_block=1)
+    assert not torch.equal(a, b)
+    assert (c.cpu() - ref).abs().max().item() <= 2e-4
+
+
+def test_guards():
+    gen = Generator(num_block=1).to(DEV)
+    x = torch.zeros(1, 3, 8, 8, device=DEV)
+    gen.train()
+    with torch.no_grad(), pytest.raises(NotImplementedError, match="BatchNorm"):
+        gen(x)
+    gen.eval()
+    with pytest.raises(NotImplementedError, match="autograd"):
+        gen(x)
+
+
+def test_discriminator_eval_matches_reference(golden_dir):
+    g = _load(golden_dir, "disc_p32_b3.npz")
+    d = Discriminator(patch_size=int(g["patch"]))
+    d.load_state_dict(O.to_torch(W.discriminator_weights(seed=int(g["wseed"]), patch_size=int(g["patch"]))))
+    d = d.to(DEV).eval()
+    with torch.no_grad():
+        p = d(torch.from_numpy(g["x"]).to(DEV))
+    assert p.shape == g["prob_eval"].shape
+    assert np.abs(p.cpu().numpy() - g["prob_eval"]).max() <= 1e-5
+    d.set_compute("bf16")
+    with torch.no_grad():
+        pb = d(torch.from_numpy(g["x"]).to(DEV))
+    assert np.abs(pb.cpu().numpy() - g["prob_eval"]).max() <= 2e-2

@@ -1,0 +1,166 @@
+"""GPU: single-kernel parity through the C ABI against a CPU torch restatement of the same fused op
+(conv -> scale/shift -> act -> +residual -> sub-pixel store).  Integer/index work (layouts, shuffles,
+slices) must be exact; f32 MFMA within summation-order error; bf16 within one output rounding."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from srmi import _lib as L
+from srmi import functional as Fn
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _rng(seed):
+    return np.random.Generator(np.random.PCG64(seed))
+
+
+def _ref_fused(x_nchw, w, scale, shift, act, act_param, alpha, residual_nchw, stride, pad, r, dcr):
+    """CPU f64 restatement of one srmi_conv_desc."""
+    z = F.conv2d(x_nchw.double(), w.double(), None, stride=stride, padding=pad)
+    z = z * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    if act == L.ACT_PRELU:
+        a = alpha.double().view(1, -1, 1, 1) if alpha.numel() > 1 else alpha.double()
+        z = torch.where(z >= 0, z, z * a)
+    elif act == L.ACT_LRELU:
+        z = F.leaky_relu(z, act_param)
+    elif act == L.ACT_RELU:
+        z = F.relu(z)
+    elif act == L.ACT_TANH:
+        z = torch.tanh(z)
+    elif act == L.ACT_SIGMOID:
+        z = torch.sigmoid(z)
+    if r > 1:
+        if dcr:   # depth_to_space: channel = (i*r+j)*C + c
+            n, c, h, wd = z.shape
+            cf = c // (r * r)
+            z = z.view(n, r, r, cf, h, wd).permute(0, 3, 4, 1, 5, 2).reshape(n, cf, h * r, wd * r)
+        else:
+            z = F.pixel_shuffle(z, r)
+    if residual_nchw is not None:
+        z = z + residual_nchw.double()
+    return z
+
+
+def _run_case(N, H, W, Cin, Cout, k, *, stride=1, act=L.ACT_NONE, act_param=0.0, alpha_pc=0, residual=False, r=1,
+              dcr=False, io=torch.float32, compute=L.COMPUTE_F32, in_layout=L.NHWC, out_layout=L.NHWC,
+              in_cs=0, out_cs=0, out_co=0, seed=0):
+    g = _rng(seed)
+    x = torch.from_numpy(g.uniform(-1, 1, (N, Cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((g.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32))
+    scale = torch.from_numpy(g.uniform(0.5, 1.5, Cout).astype(np.float32))
+    shift = torch.from_numpy(g.uniform(-0.3, 0.3, Cout).astype(np.float32))
+    alpha = torch.from_numpy(g.uniform(0.05, 0.4, Cout if alpha_pc else 1).astype(np.float32))
+    bf = io == torch.bfloat16
+    if bf:                       # the kernel sees bf16-rounded activations / weights: so does the reference
+        x = x.bfloat16().float()
+        if compute == L.COMPUTE_BF16:
+            w = w.bfloat16().float()
+    pad = k // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    Cf = Cout // (r * r)
+    res = None
+    if residual:
+        res = torch.from_numpy(g.uniform(-1, 1, (N, Cf, Ho * r, Wo * r)).astype(np.float32))
+        if bf:
+            res = res.bfloat16().float()
+    ref = _ref_fused(x, w, scale, shift, act, act_param, alpha, res, stride, pad, r, dcr)
+
+    dio = L.BF16 if bf else L.F32
+    desc = Fn.make_desc(N, H, W, Cin, Cout, k, stride=stride, in_dtype=dio, out_dtype=dio, res_dtype=dio,
+                        in_layout=in_layout, out_layout=out_layout, compute=compute, act=act, act_param=act_param,
+                        alpha_per_channel=alpha_pc, shuffle=r, shuffle_order=L.SHUFFLE_DCR if dcr else L.SHUFFLE_CRD,
+                        in_cstride=in_cs, out_cstride=out_cs, out_coffset=out_co)
+    # device buffers
+    if in_layout == L.NHWC:
+        cs = in_cs or Cin
+        xd = torch.full((N, H, W, cs), 7.0, dtype=io)          # poison the unused slice channels
+        xd[..., :Cin] = x.permute(0, 2, 3, 1).to(io)
+    else:
+        xd = x.to(io)
+    xd = xd.to(DEV)
+    wp = Fn.pack_weights(desc, w.to(DEV))
+    if out_layout == L.NHWC:
+        ocs = out_cs or Cf
+        yd = torch.full((N, Ho * r, Wo * r, ocs), -5.0, dtype=io, device=DEV)
+        rd = res.permute(0, 2, 3, 1).contiguous().to(io).to(DEV) if residual else None
+    else:
+        yd = torch.full((N, Cf, Ho * r, Wo * r), -5.0, dtype=io, device=DEV)
+        rd = res.to(io).to(DEV) if residual else None
+    Fn.conv2d_fused(desc, xd, wp, scale.to(DEV), shift.to(DEV), alpha.to(DEV), rd, out=yd)
+    torch.cuda.synchronize()
+    y = yd.float().cpu()
+    if out_layout == L.NHWC:
+        got = y[..., out_co:out_co + Cf].permute(0, 3, 1, 2)
+        # channels outside the written slice must be untouched
+        if out_cs:
+            mask = torch.ones(out_cs, dtype=torch.bool)
+            mask[out_co:out_co + Cf] = False
+            assert torch.all(y[..., mask] == -5.0)
+    else:
+        got = y
+    err = (got.double() - ref).abs()
+    tol = 3e-5 if not bf else 2.0 ** -8 * (ref.abs() + 1.0)     # bf16: one rounding of the output (+ of x)
+    assert torch.all(err <= tol), f"max err {err.max().item():.3e} ({L.kernel_name(desc)})"
+    return L.kernel_name(desc)
+
+
+def test_layout_convert_exact():
+    g = _rng(5)
+    x = torch.from_numpy(g.uniform(-1, 1, (2, 5, 7, 9)).astype(np.float32)).to(DEV)
+    nhwc = Fn.layout_convert(x, 2, 5, 7, 9, L.NCHW, L.NHWC, torch.float32)
+    assert torch.equal(nhwc, x.permute(0, 2, 3, 1).contiguous())
+    back = Fn.layout_convert(nhwc, 2, 5, 7, 9, L.NHWC, L.NCHW, torch.float32)
+    assert torch.equal(back, x)
+    b = Fn.layout_convert(x, 2, 5, 7, 9, L.NCHW, L.NHWC, torch.bfloat16)
+    assert torch.equal(b, x.permute(0, 2, 3, 1).contiguous().bfloat16())     # RNE cast matches torch's
+
+
+@pytest.mark.parametrize("case", [
+    dict(N=1, H=9, W=7, Cin=3, Cout=64, k=9, act=L.ACT_PRELU, in_layout=L.NCHW),                # conv01
+    dict(N=2, H=11, W=13, Cin=64, Cout=64, k=3, act=L.ACT_PRELU),                               # ResBlock conv 1
+    dict(N=2, H=11, W=13, Cin=64, Cout=64, k=3, residual=True),                                 # ResBlock conv 2
+    dict(N=1, H=6, W=5, Cin=64, Cout=256, k=3, act=L.ACT_PRELU, r=2),                           # Upsampler x2
+    dict(N=1, H=6, W=5, Cin=64, Cout=576, k=3, act=L.ACT_PRELU, r=3),                           # Upsampler x3
+    dict(N=1, H=6, W=5, Cin=64, Cout=256, k=3, act=L.ACT_PRELU, alpha_pc=1, r=2, dcr=True),     # Keras depth_to_space
+    dict(N=2, H=10, W=12, Cin=64, Cout=3, k=3, act=L.ACT_TANH, out_layout=L.NCHW),              # last_conv
+    dict(N=2, H=12, W=12, Cin=64, Cout=64, k=3, stride=2, act=L.ACT_LRELU, act_param=0.01),     # D stride-2
+    dict(N=2, H=9, W=9, Cin=128, Cout=128, k=3, stride=2, act=L.ACT_LRELU, act_param=0.01),     # odd size stride 2
+    dict(N=3, H=1, W=1, Cin=2048, Cout=1024, k=1, act=L.ACT_LRELU, act_param=0.01),             # Linear as 1x1
+    dict(N=3, H=1, W=1, Cin=1024, Cout=1, k=1, act=L.ACT_SIGMOID),                              # Linear -> sigmoid
+    dict(N=1, H=12, W=12, Cin=1, Cout=128, k=9, act=L.ACT_RELU),                                # SRCNN layer 1
+    dict(N=1, H=12, W=12, Cin=64, Cout=1, k=5),                                                 # SRCNN layer 3
+    dict(N=1, H=8, W=8, Cin=96, Cout=32, k=3, act=L.ACT_LRELU, act_param=0.2, in_cs=160, out_cs=160, out_co=96),  # RRDB dense
+    dict(N=1, H=5, W=40, Cin=20, Cout=40, k=3, act=L.ACT_RELU),                                 # ragged channels
+])
+def test_generic_f32_kernel(case):
+    assert _run_case(**case) == "generic_f32"
+
+
+@pytest.mark.parametrize("case", [
+    dict(N=2, H=11, W=13, Cin=64, Cout=64, k=3, act=L.ACT_PRELU),
+    dict(N=1, H=6, W=5, Cin=64, Cout=256, k=3, act=L.ACT_PRELU, r=2),
+    dict(N=2, H=10, W=12, Cin=64, Cout=3, k=3, act=L.ACT_TANH, out_layout=L.NCHW),
+])
+def test_generic_kernel_bf16_storage(case):
+    assert _run_case(io=torch.bfloat16, **case) == "generic_f32"
+
+
+@pytest.mark.parametrize("case", [
+    dict(N=2, H=11, W=13, Cout=64, act=L.ACT_PRELU),                          # small tile, ragged edges
+    dict(N=2, H=11, W=13, Cout=64, residual=True),
+    dict(N=1, H=4, W=32, Cout=64, act=L.ACT_LRELU, act_param=0.2),            # exactly one small tile
+    dict(N=1, H=13, W=100, Cout=64, act=L.ACT_PRELU, residual=True),          # big 6x96 tile, ragged
+    dict(N=2, H=6, W=96, Cout=64, act=L.ACT_RELU),                            # exactly one big tile per image
+    dict(N=1, H=24, W=192, Cout=64, act=L.ACT_PRELU, alpha_pc=1),
+    dict(N=1, H=7, W=9, Cout=256, act=L.ACT_PRELU, r=2),                      # PixelShuffle store (CRD)
+    dict(N=1, H=12, W=97, Cout=256, act=L.ACT_PRELU, r=2),
+    dict(N=1, H=7, W=9, Cout=256, act=L.ACT_PRELU, alpha_pc=1, r=2, dcr=True),  # depth_to_space store (DCR)
+    dict(N=1, H=9, W=20, Cout=128, act=L.ACT_LRELU, act_param=0.01),          # D conv 64->128
+    dict(N=1, H=8, W=8, Cout=64, act=L.ACT_LRELU, act_param=0.2, in_cs=160, out_cs=160, out_co=64),  # concat slices
+])
+def test_c64_bf16_kernel(case):
+    name = _run_case(Cin=64, k=3, io=torch.bfloat16, compute=L.COMPUTE_BF16, **case)
+    assert name == "c64_bf16"
