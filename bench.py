@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""Headline benchmark: x4 SR output megapixels / second of the SRResNet generator forward
+(BASELINE.json metric; workload = configs[0] "SRResNet x4 generator (16 res blocks, 64ch, 2x
+PixelShuffle) forward, batch 16x3x96x96 LR, random init", the configuration north_star's target
+">=60 % of peak bf16 MFMA" is quoted on).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--compute bf16|fp32]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step = one `Generator.forward(lr) -> (sr, feat)` through the drop-in module surface (NCHW f32 in
+HBM -> NCHW f32 out), i.e. 37 fused conv launches + 1 re-layout of `feat`.  Inference shards by batch
+item with no collective: every rank runs the same per-GPU batch (weak scaling), the
+timed region is bracketed by barrier + synchronize, the slowest rank's time is used, and `value` is
+the whole-job aggregate.
+
+Extra objects on the JSON line:
+  roofline     - the dominant kernel (conv_c64_kernel, all 35 launches per step) against the dense
+                 bf16 MFMA peak; its time is measured with HIP events on the launch stream.
+  cpu_baseline - the oracle (plain torch.nn.functional restatement, pinned to the reference) timed on
+                 this box's host cores, rank 0, N=1 only.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "super-resolution_amd"))
+
+import numpy as np
+import torch
+
+PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
+PEAK_F32_MFMA_TFLOPS = 157.3  # exact-f32 MFMA
+BATCH, LR_H, LR_W, NUM_BLOCK = 16, 96, 96, 16
+FLOP_PER_OUT_PIXEL = 249_624  # SURVEY App. A / BASELINE.md section 4 (conv MACs x 2 only)
+
+
+def conv_flops(d):
+    """algorithmic FLOPs of one fused conv launch: 2 * N*Ho*Wo * Cout * kh*kw*Cin."""
+    ho = (d.H + 2 * d.pad - d.kh) // d.stride + 1
+    wo = (d.W + 2 * d.pad - d.kw) // d.stride + 1
+    return 2.0 * d.N * ho * wo * d.Cout * d.kh * d.kw * d.Cin
+
+
+def synthetic_state(gen, seed=0):
+    """Random-init weights of the architecture (no checkpoints exist offline): conv W ~ N(0, 0.75/sqrt(fan_in)),
+    non-trivial BatchNorm statistics, PReLU 0.25.  Values do not affect timing; they keep activations O(1)."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for k, v in gen.state_dict().items():
+        if k.endswith("num_batches_tracked"):
+            sd[k] = v.clone()
+        elif k.endswith("running_var"):
+            sd[k] = torch.empty(v.shape).uniform_(0.5, 1.5, generator=g)
+        elif k.endswith("running_mean"):
+            sd[k] = torch.randn(v.shape, generator=g) * 0.1
+        elif v.dim() == 4:
+            sd[k] = torch.randn(v.shape, generator=g) * (0.75 / (v.shape[1] * v.shape[2] * v.shape[3]) ** 0.5)
+        elif k.endswith("bias"):
+            sd[k] = torch.empty(v.shape).uniform_(-0.1, 0.1, generator=g)
+        elif v.numel() == 1:
+            sd[k] = torch.full(v.shape, 0.25)
+        else:
+            sd[k] = torch.empty(v.shape).uniform_(0.5, 1.5, generator=g)
+    return sd
+
+
+def build_generator(device, compute):
+    from srmi.srgan_model import Generator
+    gen = Generator(num_block=NUM_BLOCK)
+    sd = synthetic_state(gen, seed=0)
+    gen.load_state_dict(sd)
+    x = torch.empty((BATCH, 3, LR_H, LR_W)).uniform_(-1.0, 1.0, generator=torch.Generator().manual_seed(1))
+    return gen.to(device).eval().set_compute(compute), x.to(device), sd, x
+
+
+def per_kernel_times(gen, x, reps):
+    """HIP-event time of every launch of one forward, averaged over `reps` instrumented forwards.
+    Launches go to torch's current stream, which is the stream the events are recorded on."""
+    from srmi import _lib as L
+    from srmi import functional as Fn
+    plan = gen._plans.get(gen, x.shape[0], x.shape[2], x.shape[3], 1 if gen.compute == "bf16" else 0)
+    lib = L.load()
+    n = plan.n
+    plan.args[0].x = x.data_ptr()
+    sr = torch.empty(plan.sr_shape, dtype=torch.float32, device=x.device)
+    plan.args[n - 1].y = sr.data_ptr()
+    tot = np.zeros(n)
+    st = Fn.stream_ptr()
+    for _ in range(reps):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        ev[0].record()
+        for i in range(n):
+            L.check(lib.srmi_conv2d_fwd(C.byref(plan.args[i]), st))
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        tot += np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(n)])
+    return plan, tot / reps   # ms per launch
+
+
+def cpu_baseline(threads, sd, x):
+    """The oracle (oracle/srgan_oracle.py: plain torch.nn.functional restatement, pinned bit-exact to the
+    imported reference in the build container) on the host cores, same weights and inputs as the GPU leg."""
+    from oracle import srgan_oracle as O
+    torch.set_num_threads(threads)
+    times = []
+    with torch.no_grad():
+        O.generator_forward(sd, x, num_block=NUM_BLOCK)          # warm-up
+        for _ in range(3):
+            t0 = time.perf_counter()
+            O.generator_forward(sd, x, num_block=NUM_BLOCK)
+            times.append(time.perf_counter() - t0)
+    t = float(np.median(times))
+    mp = BATCH * (4 * LR_H) * (4 * LR_W) / 1e6
+    return {"value": round(mp / t, 4), "unit": "MP/s", "cores": threads, "kind": "port",
+            "sample": f"1 warm-up + 3 timed forwards of the same 16x3x96x96 batch, median {t:.2f} s, fp32, "
+                      f"torch {torch.__version__} CPU, torch.get_num_threads()={torch.get_num_threads()}"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+
+    gen, x, sd_cpu, x_cpu = build_generator(dev, args.compute)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            gen(x)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sr, feat = gen(x)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    out_mp_per_step = world * BATCH * (4 * LR_H) * (4 * LR_W) / 1e6
+    value = out_mp_per_step * args.steps / elapsed
+    ms = elapsed / args.steps * 1e3
+
+    result = None
+    if rank == 0:
+        # ---- roofline of the dominant kernel (HIP events, same process, same data) -------------
+        with torch.no_grad():
+            plan, kms = per_kernel_times(gen, x, reps=max(5, min(20, args.steps)))
+        dom = "c64_bf16" if args.compute == "bf16" else "generic_f32"
+        idx = [i for i, k in enumerate(plan.kernels) if k == dom]
+        flops = sum(conv_flops(plan.args[i].d) for i in idx)
+        t_dom = float(sum(kms[i] for i in idx)) * 1e-3
+        peak = PEAK_BF16_TFLOPS if args.compute == "bf16" else PEAK_F32_MFMA_TFLOPS
+        achieved = flops / t_dom / 1e12
+        per_layer = {}
+        for i, k in enumerate(plan.kernels):
+            d = plan.args[i].d
+            key = f"{k}:{d.Cin}->{d.Cout}@{d.H}x{d.W}k{d.kh}"
+            e = per_layer.setdefault(key, [0, 0.0, 0.0])
+            e[0] += 1; e[1] += kms[i]; e[2] += conv_flops(d)
+        layers = {k: {"launches": v[0], "ms": round(v[1], 4), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
+                  for k, v in per_layer.items()}
+        roofline = {"bound": "mfma", "kernel": "conv_c64_kernel" if dom == "c64_bf16" else "conv_generic_kernel",
+                    "launches_per_step": len(idx), "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": None,
+                    "avg_launch_us": round(t_dom / len(idx) * 1e6, 2),
+                    "flops_per_launch_avg": flops / len(idx),
+                    "whole_step_frac": round(value / world * 1e6 * FLOP_PER_OUT_PIXEL / 1e12 / peak, 4),
+                    "sum_kernel_ms": round(float(kms.sum()), 4), "layers": layers,
+                    "method": "HIP events around every launch of instrumented forwards run right after the "
+                              "timed region (same process, stream, data); achieved = sum of algorithmic conv "
+                              "FLOPs of this kernel's launches / sum of their event times"}
+        result = {
+            "metric": "x4 SR output megapixels/sec (whole node)", "value": round(value, 2), "unit": "MP/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16" if args.compute == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": "SRResNet x4 generator forward (16 res blocks, 64ch, 2x PixelShuffle), "
+                                   "batch 16x3x96x96 LR per GPU -> 16x3x384x384, random-init recipe weights, "
+                                   "inputs resident in HBM, drop-in Generator.forward incl. NCHW<->NHWC edges",
+                       "per_gpu_batch": BATCH, "lr": [LR_H, LR_W], "parallelism": f"batch-sharded x{world}, no collective"},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            threads = max(1, min(16, os.cpu_count() or 1))
+            result["cpu_baseline"] = cpu_baseline(threads, sd_cpu, x_cpu)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result), flush=True)
+
+
+if __name__ == "__main__":
+    main()

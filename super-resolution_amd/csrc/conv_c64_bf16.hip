@@ -20,6 +20,8 @@
 //     sub-pixel modes one 64-channel chunk is exactly one 128-B output pixel;
 //   * each wave keeps PT pixel tiles x 4 channel tiles of f32 accumulators (PT = 9 for the
 //     6 x 96 tile: 13 fragment reads feed 36 MFMAs per K-step).
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace srmi {
@@ -34,12 +36,29 @@ struct C64Params {
     int act; float act_param; int alpha_pc;
     int mode;  // 0 plain, 1 PixelShuffle(2) CRD, 2 depth_to_space(2) DCR
     int tiles_x, tiles_y;
+    int dbg;  // ablation switches (SRMI_DBG env, investigation only): 1 skip staging, 2 skip K loop, 4 skip epilogue
 };
 
 
 // conv-channel index of (chunk s, channel-within-chunk cl)
 __device__ __forceinline__ int c64_conv_channel(int mode, int s, int cl) {
     return mode == 1 ? 4 * cl + s : 64 * s + cl;
+}
+
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+constexpr int C64_WRING = 4;          // weight ring slots (one 3x3 tap = 8 KiB of A fragments per slot)
+constexpr int C64_TAP_BYTES = 8192;   // 2 k-steps x 4 channel tiles x 64 lanes x 16 B
+
+// scheduling directive: NR groups of {1 LDS read, ~NM/NR MFMAs} (compile-time only, no code emitted)
+template <int I, int NR, int NM>
+__device__ __forceinline__ void sched_interleave() {
+    if constexpr (I < NR) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NM / NR + (I < NM % NR ? 1 : 0), 0);
+        sched_interleave<I + 1, NR, NM>();
+    }
 }
 
 template <int TH, int TWT>
@@ -49,8 +68,11 @@ __global__ __launch_bounds__(256, 1) void conv_c64_kernel(C64Params p) {
     static_assert(NPT % 4 == 0, "pixel tiles must split evenly over 4 waves");
     constexpr int PT = NPT / 4;
     constexpr int ROWP = (TW + 2 + 15) / 16 * 16;  // LDS row pitch in pixels (multiple of 16: swizzle independent of dy)
-    constexpr int LDS_BYTES = (TH + 2) * ROWP * 128;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[LDS_BYTES];
+    constexpr int IN_BYTES = (TH + 2) * ROWP * 128;
+    // ONE shared array (input tile | weight ring): a second __shared__ object next to an LDS-DMA
+    // target makes hipcc drain vmcnt before every ds_read (cdna guide, "three .s-level traps").
+    __shared__ __attribute__((aligned(16))) unsigned char lds[IN_BYTES + C64_WRING * C64_TAP_BYTES];
+    unsigned char* const wring = lds + IN_BYTES;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -64,23 +86,66 @@ __global__ __launch_bounds__(256, 1) void conv_c64_kernel(C64Params p) {
     const int n = b / p.tiles_y;
     const int y0 = ty * TH, x0 = tx * TW;
 
+    // ---- weight stream: packed A fragments, one tap (8 KiB) per ring slot, moved by LDS-DMA ------
+    // wave w copies KiB 2w and 2w+1 of each tap; the LDS image is lane-linear (= fragment order).
+    const int ntap = p.nchunk * 9;
+    const unsigned char* wsrc = (const unsigned char*)p.w + (wave * 2) * 1024 + lane * 16;
+    // The DMA is issued from inline asm on purpose: hipcc tracks a builtin LDS-DMA as an LDS write that
+    // may alias every later ds_read of the same array and drains vmcnt(0) in front of it, which would
+    // serialise the ring.  Here the hand-off is ordered by hand (counted vmcnt + s_barrier below).
+    const unsigned wring_lds = (unsigned)(uintptr_t)(lptr_t)wring;
+    auto issue_tap = [&](int g) {
+        const unsigned char* src = wsrc + (size_t)g * C64_TAP_BYTES;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(
+            wring_lds + (unsigned)((g & (C64_WRING - 1)) * C64_TAP_BYTES + (wave * 2) * 1024));
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %3\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off\n\t"
+            "s_add_u32 m0, m0, 0x400\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %2, off\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(src), "v"(src + 1024), "s"(dst)
+            : "memory", "scc");
+    };
+    issue_tap(0);
+    if (ntap > 1) issue_tap(1);
+    if (ntap > 2) issue_tap(2);
+
+    if (!(p.dbg & 1))
     // ---- stage the input halo tile: global (NHWC bf16) -> registers -> swizzled LDS ----------
+    // All loads are issued before the first is consumed (clamped address + select, no branches):
+    // one HBM/L2 round trip for the whole tile instead of one per 16-B chunk.
     {
         constexpr int NCH = (TH + 2) * (TW + 2) * 8;  // 16-B chunks
+        constexpr int NIT = (NCH + 255) / 256;
         const bf16_t* xin = p.x + (size_t)n * p.H * p.W * p.in_cs;
-#pragma unroll 4
-        for (int idx = tid; idx < NCH; idx += 256) {
+        u32x4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = min(tid + it * 256, NCH - 1);
+            const int pp = idx >> 3, ch = idx & 7;
+            const int row = pp / (TW + 2), col = pp - row * (TW + 2);
+            const int gy = min(max(y0 - 1 + row, 0), p.H - 1), gx = min(max(x0 - 1 + col, 0), p.W - 1);
+            v[it] = *(const u32x4*)(xin + ((size_t)gy * p.W + gx) * p.in_cs + ch * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 256;
             const int pp = idx >> 3, ch = idx & 7;
             const int row = pp / (TW + 2), col = pp - row * (TW + 2);
             const int gy = y0 - 1 + row, gx = x0 - 1 + col;
-            u32x4 v = {0u, 0u, 0u, 0u};
-            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-                v = *(const u32x4*)(xin + ((size_t)gy * p.W + gx) * p.in_cs + ch * 8);
+            const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            u32x4 z = v[it];
+            if (!ok) z = (u32x4){0u, 0u, 0u, 0u};
             const int P = row * ROWP + col;
-            *(u32x4*)(lds + P * 128 + ((ch ^ ((P >> 1) & 7)) << 4)) = v;
+            if (idx < NCH) *(u32x4*)(lds + P * 128 + ((ch ^ ((P >> 1) & 7)) << 4)) = z;
         }
     }
-    __syncthreads();
 
     // per-wave pixel tiles: tile index t = wave*PT + k -> (row, 16-col group)
     int prow[PT], pcol[PT];
@@ -91,7 +156,28 @@ __global__ __launch_bounds__(256, 1) void conv_c64_kernel(C64Params p) {
         pcol[k] = (t - prow[k] * TWT) * 16;
     }
 
-    const float alpha0 = (p.act == SRMI_ACT_PRELU && !p.alpha_pc) ? p.alpha[0] : 0.f;
+    // every activation this kernel serves is  v >= 0 ? v : v * slope  (none: 1, ReLU: 0, LeakyReLU: param,
+    // PReLU: alpha) - branch-free, so the unrolled epilogue stays small enough for the instruction cache.
+    float slope0 = 1.f;
+    if (p.act == SRMI_ACT_RELU) slope0 = 0.f;
+    else if (p.act == SRMI_ACT_LRELU) slope0 = p.act_param;
+    else if (p.act == SRMI_ACT_PRELU && !p.alpha_pc) slope0 = p.alpha[0];
+    const bool slope_pc = p.act == SRMI_ACT_PRELU && p.alpha_pc;
+
+    // input tile written (own ds_writes: lgkmcnt; the staging loads' vmcnt(0) also retired taps 0..2)
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // loop-invariant LDS byte offsets of this lane's B fragments: [pixel tile][dx], channel half 0
+    // (half 1 flips bit 6: chunk index cb = 4 only toggles bit 2 of the swizzled chunk).
+    int boff[PT][3];
+#pragma unroll
+    for (int k = 0; k < PT; ++k)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int P = prow[k] * ROWP + pcol[k] + pl + dx;
+            boff[k][dx] = P * 128 + ((q ^ ((P >> 1) & 7)) << 4);
+        }
 
     for (int s = 0; s < p.nchunk; ++s) {
         f32x4 acc[PT][4];
@@ -100,38 +186,52 @@ __global__ __launch_bounds__(256, 1) void conv_c64_kernel(C64Params p) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[k][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        const bf16x8* wfrag = (const bf16x8*)p.w + (size_t)s * 18 * 4 * 64 + lane;
-        bf16x8 a_cur[4], a_nxt[4];
+        // K loop = 18 steps (9 taps x 2 channel halves), fully unrolled and software-pipelined by hand:
+        // the 13 operand fragments of step j+1 are read from LDS while the 36 MFMAs of step j run
+        // (one wave per SIMD: nothing else hides the ds_read latency).  Weight taps arrive through a
+        // 4-slot LDS-DMA ring; the hand-off for tap g+1 (counted vmcnt + barrier) sits in the MIDDLE of
+        // tap g so that the first fragments of the next tap can be prefetched like any others.
+        bf16x8 afr[2][4], bfr[2][PT];
+        {
+            const unsigned char* wslot = wring + ((s * 9) & (C64_WRING - 1)) * C64_TAP_BYTES + lane * 16;
 #pragma unroll
-        for (int t = 0; t < 4; ++t) a_cur[t] = wfrag[t * 64];
-
-        // K loop: dy rolled (keeps the weight-fragment prefetch distance bounded), (dx, channel half)
-        // unrolled: the swizzle term (P>>1)&7 does not depend on dy because ROWP % 16 == 0, so the
-        // 6 LDS offsets per pixel tile are loop invariants and dy only adds a multiple of ROWP*128.
-#pragma unroll 1
-        for (int dy = 0; dy < 3; ++dy) {
-            const unsigned char* lrow = lds + dy * (ROWP * 128);
+            for (int t = 0; t < 4; ++t) afr[0][t] = *(const bf16x8*)(wslot + t * 1024);
 #pragma unroll
-            for (int kk = 0; kk < 6; ++kk) {
-                const int dx = kk >> 1;
-                const int cb = (kk & 1) * 4;
-                const int ks = dy * 6 + kk;
-                const int ksn = ks + 1 < 18 ? ks + 1 : 17;  // last prefetch re-reads step 17 (harmless)
+            for (int k = 0; k < PT; ++k) bfr[0][k] = *(const bf16x8*)(lds + boff[k][0]);
+        }
+        if (!(p.dbg & 2))
 #pragma unroll
-                for (int t = 0; t < 4; ++t) a_nxt[t] = wfrag[(ksn * 4 + t) * 64];
-                bf16x8 bfr[PT];
+        for (int j = 0; j < 18; ++j) {
+            const int tap = j >> 1, half = j & 1;
+            const int g = s * 9 + tap;
+            if (half == 1) {
+                // tap g+1 landed: own copies by counted vmcnt (tap g+2 stays in flight), the other waves'
+                // by the barrier, which also retires every wave's reads of tap g-1 -> its slot is free.
+                if (g + 2 < ntap) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (g + 3 < ntap) issue_tap(g + 3);
+            }
+            if (j + 1 < 18) {
+                const int tapn = (j + 1) >> 1, halfn = (j + 1) & 1;
+                const int dyn = tapn / 3, dxn = tapn - 3 * dyn;
+                const unsigned char* wslot =
+                    wring + ((s * 9 + tapn) & (C64_WRING - 1)) * C64_TAP_BYTES + lane * 16 + halfn * 4096;
 #pragma unroll
-                for (int k = 0; k < PT; ++k) {
-                    const int P = prow[k] * ROWP + pcol[k] + pl + dx;
-                    bfr[k] = *(const bf16x8*)(lrow + P * 128 + (((cb + q) ^ ((P >> 1) & 7)) << 4));
-                }
+                for (int t = 0; t < 4; ++t) afr[(j + 1) & 1][t] = *(const bf16x8*)(wslot + t * 1024);
 #pragma unroll
                 for (int k = 0; k < PT; ++k)
+                    bfr[(j + 1) & 1][k] =
+                        *(const bf16x8*)(lds + ((boff[k][dxn] ^ (halfn << 6)) + dyn * (ROWP * 128)));
+            }
 #pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a_cur[t], bfr[k], acc[k][t], 0, 0, 0);
+            for (int k = 0; k < PT; ++k)
 #pragma unroll
-                for (int t = 0; t < 4; ++t) a_cur[t] = a_nxt[t];
+                for (int t = 0; t < 4; ++t)
+                    acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[j & 1][t], bfr[j & 1][k], acc[k][t], 0, 0, 0);
+            if (j + 1 < 18) {
+                // interleave: one LDS read per ~3 MFMAs (13 reads under 36 MFMAs)
+                sched_interleave<0, 4 + PT, 4 * PT>();
             }
         }
 
@@ -142,9 +242,10 @@ __global__ __launch_bounds__(256, 1) void conv_c64_kernel(C64Params p) {
             const int co = c64_conv_channel(p.mode, s, 16 * q + e);
             sc[e] = p.scale[co];
             sh[e] = p.shift[co];
-            al[e] = (p.act == SRMI_ACT_PRELU && p.alpha_pc) ? p.alpha[co] : alpha0;
+            al[e] = slope_pc ? p.alpha[co] : slope0;
         }
         const int si = s >> 1, sj = s & 1;
+        if (!(p.dbg & 4))
 #pragma unroll
         for (int k = 0; k < PT; ++k) {
             const int oy = y0 + prow[k], ox = x0 + pcol[k] + pl;
@@ -163,7 +264,8 @@ __global__ __launch_bounds__(256, 1) void conv_c64_kernel(C64Params p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int c = 4 * t + e;
-                    v[c] = apply_act(acc[k][t][e] * sc[c] + sh[c], p.act, p.act_param, al[c]);
+                    const float z = acc[k][t][e] * sc[c] + sh[c];
+                    v[c] = z >= 0.f ? z : z * al[c];
                 }
             if (p.res) {
                 const int Cf = p.mode == 0 ? p.Cout : 64;
@@ -263,6 +365,7 @@ int c64_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     p.in_cs = g.in_cs; p.out_cs = g.out_cs; p.out_co = d.out_coffset;
     p.act = d.act; p.act_param = d.act_param; p.alpha_pc = d.alpha_per_channel;
     p.mode = c64_mode(d);
+    { const char* e = getenv("SRMI_DBG"); p.dbg = e ? atoi(e) : 0; }
     if (d.N == 0 || d.H == 0 || d.W == 0) return SRMI_OK;
     // tile choice: 6 x 96 (9 pixel tiles per wave) when the image is wide enough to fill it,
     // otherwise 4 x 32 (2 pixel tiles per wave) so small images still spread over the CUs.
