@@ -77,7 +77,18 @@ int conv_geom(const srmi_conv_desc& d, ConvGeom* g) {
 
 int select_kernel(const srmi_conv_desc& d) {
     if (c64_supported(d)) return K_C64_BF16;
+    if (thin_supported(d)) return K_THIN_BF16;
+    if (k9c3_supported(d)) return K_K9C3_BF16;
     return K_GENERIC_F32;
+}
+
+const char* kernel_label(int k) {
+    switch (k) {
+        case K_C64_BF16: return "c64_bf16";
+        case K_THIN_BF16: return "c64_thin_bf16";
+        case K_K9C3_BF16: return "k9c3_bf16";
+        default: return "generic_f32";
+    }
 }
 
 static int conv_fwd_one(const srmi_conv_args* a, hipStream_t s) {
@@ -96,6 +107,8 @@ static int conv_fwd_one(const srmi_conv_args* a, hipStream_t s) {
     }
     switch (select_kernel(a->d)) {
         case K_C64_BF16: return c64_launch(*a, g, s);
+        case K_THIN_BF16: return thin_launch(*a, g, s);   // rejects a residual (SRMI_EUNSUPPORTED)
+        case K_K9C3_BF16: return k9c3_launch(*a, g, s);
         default: return generic_launch(*a, g, s);
     }
 }
@@ -115,8 +128,7 @@ int srmi_conv2d_kernel_name(const srmi_conv_desc* d, char* buf, size_t buf_len) 
     ConvGeom g;
     int rc = conv_geom(*d, &g);
     if (rc) return rc;
-    const char* nm = select_kernel(*d) == K_C64_BF16 ? "c64_bf16" : "generic_f32";
-    snprintf(buf, buf_len, "%s", nm);
+    snprintf(buf, buf_len, "%s", kernel_label(select_kernel(*d)));
     return SRMI_OK;
 }
 
@@ -125,7 +137,12 @@ int srmi_conv2d_packed_weight_bytes(const srmi_conv_desc* d, size_t* bytes) {
     ConvGeom g;
     int rc = conv_geom(*d, &g);
     if (rc) return rc;
-    *bytes = select_kernel(*d) == K_C64_BF16 ? c64_packed_bytes(*d) : generic_packed_bytes(*d);
+    switch (select_kernel(*d)) {
+        case K_C64_BF16: *bytes = c64_packed_bytes(*d); break;
+        case K_THIN_BF16: *bytes = thin_packed_bytes(*d); break;
+        case K_K9C3_BF16: *bytes = k9c3_packed_bytes(*d); break;
+        default: *bytes = generic_packed_bytes(*d);
+    }
     return SRMI_OK;
 }
 
@@ -135,7 +152,12 @@ int srmi_conv2d_pack_weights(const srmi_conv_desc* d, const float* w_oihw, void*
     int rc = conv_geom(*d, &g);
     if (rc) return rc;
     hipStream_t s = (hipStream_t)stream;
-    return select_kernel(*d) == K_C64_BF16 ? c64_pack(*d, w_oihw, w_packed, s) : generic_pack(*d, w_oihw, w_packed, s);
+    switch (select_kernel(*d)) {
+        case K_C64_BF16: return c64_pack(*d, w_oihw, w_packed, s);
+        case K_THIN_BF16: return thin_pack(*d, w_oihw, w_packed, s);
+        case K_K9C3_BF16: return k9c3_pack(*d, w_oihw, w_packed, s);
+        default: return generic_pack(*d, w_oihw, w_packed, s);
+    }
 }
 
 int srmi_conv2d_fwd(const srmi_conv_args* a, void* stream) { return conv_fwd_one(a, (hipStream_t)stream); }

@@ -1,0 +1,149 @@
+// Pieces shared by the bf16 MFMA conv kernels that produce 64-channel chunks (conv_c64_bf16.hip,
+// conv_k9c3_bf16.hip): output-channel permutation, epilogue-parameter staging, fused epilogue.
+#pragma once
+#include "common.h"
+
+namespace srmi {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(1))) const void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+// store modes
+enum { C64_PLAIN = 0, C64_CRD = 1, C64_DCR = 2 };
+
+// conv-channel index of (chunk s, channel-within-chunk cl)
+__host__ __device__ __forceinline__ int c64_conv_channel(int mode, int s, int cl) {
+    return mode == C64_CRD ? 4 * cl + s : 64 * s + cl;
+}
+
+// MFMA A-row r (0..15) of channel tile t (0..3)  ->  channel-within-chunk.
+// The accumulator layout of v_mfma_f32_16x16x32 gives lane (pixel pl, group q) rows 4q..4q+3 of every
+// tile; with this map those 16 values are channels 8q..8q+7 and 32+8q..32+8q+7, so the four lanes of a
+// pixel write 64 contiguous bytes per 16-B store instruction (two instructions fill the 128-B pixel).
+__host__ __device__ __forceinline__ int c64_row_to_cl(int t, int r) {
+    return 32 * (t >> 1) + 8 * (r >> 2) + 4 * (t & 1) + (r & 3);
+}
+
+struct C64Epi {
+    const float* scale; const float* shift; const float* alpha;
+    const bf16_t* res; bf16_t* y;
+    int H, W, Cout, out_cs, out_co, mode;
+    int act; float act_param; int alpha_pc;
+};
+
+constexpr int C64_MAX_CHUNKS = 16;                       // Cout <= 1024
+constexpr int C64_PAR_BYTES = C64_MAX_CHUNKS * 3 * 64 * 4;  // per chunk: scale[64] | shift[64] | slope[64]
+
+// Every activation these kernels serve is  v >= 0 ? v : v * slope  (none: 1, ReLU: 0, LeakyReLU: param,
+// PReLU: alpha): branch-free, which keeps the unrolled epilogue small (instruction cache).
+// Stage scale / shift / slope of all chunks into LDS in kernel channel order, once per workgroup.
+__device__ __forceinline__ void c64_stage_params(float* par, const C64Epi& e, int nchunk, int tid, int nthreads) {
+    float slope0 = 1.f;
+    if (e.act == SRMI_ACT_RELU) slope0 = 0.f;
+    else if (e.act == SRMI_ACT_LRELU) slope0 = e.act_param;
+    else if (e.act == SRMI_ACT_PRELU && !e.alpha_pc) slope0 = e.alpha[0];
+    const bool pc = e.act == SRMI_ACT_PRELU && e.alpha_pc;
+    for (int i = tid; i < nchunk * 64; i += nthreads) {
+        const int s = i >> 6, cl = i & 63;
+        const int co = c64_conv_channel(e.mode, s, cl);
+        float* ps = par + s * 192;
+        ps[cl] = e.scale[co];
+        ps[64 + cl] = e.shift[co];
+        ps[128 + cl] = pc ? e.alpha[co] : slope0;
+    }
+}
+
+// Fused epilogue of one 64-channel chunk: scale/shift -> slope activation -> +residual -> bf16 store
+// (plain NHWC channel slice, or one sub-pixel of a PixelShuffle(2)/depth_to_space(2) output).
+// acc[k][t][e] = channel 32*(t>>1) + 8q + 4*(t&1) + e of pixel pl of this wave's pixel tile k.
+template <int PT>
+__device__ __forceinline__ void c64_epilogue(const f32x4 (&acc)[PT][4], const float* par_s, const C64Epi& o, int s,
+                                             int n, int y0, int x0, const int (&prow)[PT], const int (&pcol)[PT],
+                                             int pl, int q) {
+    float sc[16], sh[16], sl[16];
+#pragma unroll
+    for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+        for (int v4 = 0; v4 < 2; ++v4) {
+            const int c = 32 * hi + 8 * q + 4 * v4;
+            const f32x4 a = *(const f32x4*)(par_s + c);
+            const f32x4 bsh = *(const f32x4*)(par_s + 64 + c);
+            const f32x4 csl = *(const f32x4*)(par_s + 128 + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sc[8 * hi + 4 * v4 + e] = a[e];
+                sh[8 * hi + 4 * v4 + e] = bsh[e];
+                sl[8 * hi + 4 * v4 + e] = csl[e];
+            }
+        }
+    const int si = s >> 1, sj = s & 1;
+    const int Cf = o.mode == C64_PLAIN ? o.Cout : 64;
+    const int cbase = (o.mode == C64_PLAIN ? 64 * s : 0) + 8 * q;
+    size_t pix[PT];
+    bool ok[PT];
+#pragma unroll
+    for (int k = 0; k < PT; ++k) {
+        const int oy = y0 + prow[k], ox = x0 + pcol[k] + pl;
+        ok[k] = oy < o.H && ox < o.W;
+        pix[k] = o.mode == C64_PLAIN ? ((size_t)n * o.H + oy) * o.W + ox
+                                     : ((size_t)n * 2 * o.H + 2 * oy + si) * (2 * o.W) + 2 * ox + sj;
+    }
+    u32x4 r[PT][2];
+    if (o.res) {   // all residual loads in flight before the first use
+#pragma unroll
+        for (int k = 0; k < PT; ++k) {
+            r[k][0] = (u32x4){0u, 0u, 0u, 0u};
+            r[k][1] = (u32x4){0u, 0u, 0u, 0u};
+            if (ok[k]) {
+                const bf16_t* rp = o.res + pix[k] * Cf + cbase;
+                r[k][0] = *(const u32x4*)rp;
+                r[k][1] = *(const u32x4*)(rp + 32);
+            }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < PT; ++k) {
+        float v[16];
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 4 * t + e;
+                const float z = acc[k][t][e] * sc[c] + sh[c];
+                v[c] = z >= 0.f ? z : z * sl[c];
+            }
+        if (o.res) {
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[8 * hi + 2 * e] += bf2f((bf16_t)(r[k][hi][e] & 0xffffu));
+                    v[8 * hi + 2 * e + 1] += bf2f((bf16_t)(r[k][hi][e] >> 16));
+                }
+        }
+        if (ok[k]) {
+            u32x4 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                o0[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+                o1[e] = pack_bf2(v[8 + 2 * e], v[8 + 2 * e + 1]);
+            }
+            bf16_t* op = o.y + pix[k] * o.out_cs + o.out_co + cbase;
+            *(u32x4*)op = o0;
+            *(u32x4*)(op + 32) = o1;
+        }
+    }
+}
+
+// scheduling directive: NR groups of {1 LDS read, ~NM/NR MFMAs} (compile-time only, no code emitted)
+template <int I, int NR, int NM>
+__device__ __forceinline__ void sched_interleave() {
+    if constexpr (I < NR) {
+        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, NM / NR + (I < NM % NR ? 1 : 0), 0);
+        sched_interleave<I + 1, NR, NM>();
+    }
+}
+
+}  // namespace srmi

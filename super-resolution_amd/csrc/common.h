@@ -51,7 +51,8 @@ int conv_geom(const srmi_conv_desc& d, ConvGeom* g);  // validates, fills g
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 // kernel families (dispatch.cpp decides, the .hip files implement)
-enum Kernel { K_GENERIC_F32 = 0, K_C64_BF16 = 1 };
+enum Kernel { K_GENERIC_F32 = 0, K_C64_BF16 = 1, K_THIN_BF16 = 2, K_K9C3_BF16 = 3 };
+const char* kernel_label(int k);
 int select_kernel(const srmi_conv_desc& d);
 
 // generic f32-MFMA kernel (conv_generic.hip)
@@ -64,5 +65,17 @@ bool c64_supported(const srmi_conv_desc& d);
 size_t c64_packed_bytes(const srmi_conv_desc& d);
 int c64_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s);
 int c64_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s);
+
+// bf16 MFMA kernel for 3x3 / Cin=64 / Cout<=4 (conv_thin_bf16.hip): the HBM-bound last_conv
+bool thin_supported(const srmi_conv_desc& d);
+size_t thin_packed_bytes(const srmi_conv_desc& d);
+int thin_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s);
+int thin_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s);
+
+// bf16 MFMA kernel for 9x9 / Cin<=3 / Cout=64 (conv_k9c3_bf16.hip): conv01
+bool k9c3_supported(const srmi_conv_desc& d);
+size_t k9c3_packed_bytes(const srmi_conv_desc& d);
+int k9c3_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s);
+int k9c3_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s);
 
 }  // namespace srmi

@@ -22,44 +22,23 @@
 //     6 x 96 tile: 13 fragment reads feed 36 MFMAs per K-step).
 #include <stdlib.h>
 
-#include "common.h"
+#include "c64_common.h"
 
 namespace srmi {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct C64Params {
-    const bf16_t* x; const bf16_t* w; const float* scale; const float* shift; const float* alpha;
-    const bf16_t* res; bf16_t* y;
-    int N, H, W, Cout, nchunk;
-    int in_cs, out_cs, out_co;
-    int act; float act_param; int alpha_pc;
-    int mode;  // 0 plain, 1 PixelShuffle(2) CRD, 2 depth_to_space(2) DCR
+    const bf16_t* x; const bf16_t* w;
+    C64Epi epi;   // scale/shift/alpha/residual/output, store mode (0 plain, 1 PixelShuffle(2) CRD, 2 depth_to_space(2) DCR)
+    int N, H, W, nchunk, in_cs;
     int tiles_x, tiles_y;
     int dbg;  // ablation switches (SRMI_DBG env, investigation only): 1 skip staging, 2 skip K loop, 4 skip epilogue
 };
 
 
-// conv-channel index of (chunk s, channel-within-chunk cl)
-__device__ __forceinline__ int c64_conv_channel(int mode, int s, int cl) {
-    return mode == 1 ? 4 * cl + s : 64 * s + cl;
-}
-
-typedef __attribute__((address_space(1))) const void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
 
 constexpr int C64_WRING = 4;          // weight ring slots (one 3x3 tap = 8 KiB of A fragments per slot)
 constexpr int C64_TAP_BYTES = 8192;   // 2 k-steps x 4 channel tiles x 64 lanes x 16 B
-
-// scheduling directive: NR groups of {1 LDS read, ~NM/NR MFMAs} (compile-time only, no code emitted)
-template <int I, int NR, int NM>
-__device__ __forceinline__ void sched_interleave() {
-    if constexpr (I < NR) {
-        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, NM / NR + (I < NM % NR ? 1 : 0), 0);
-        sched_interleave<I + 1, NR, NM>();
-    }
-}
 
 template <int TH, int TWT>
 __global__ __launch_bounds__(256, 1) void conv_c64_kernel(C64Params p) {
@@ -71,8 +50,9 @@ __global__ __launch_bounds__(256, 1) void conv_c64_kernel(C64Params p) {
     constexpr int IN_BYTES = (TH + 2) * ROWP * 128;
     // ONE shared array (input tile | weight ring): a second __shared__ object next to an LDS-DMA
     // target makes hipcc drain vmcnt before every ds_read (cdna guide, "three .s-level traps").
-    __shared__ __attribute__((aligned(16))) unsigned char lds[IN_BYTES + C64_WRING * C64_TAP_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[IN_BYTES + C64_WRING * C64_TAP_BYTES + C64_PAR_BYTES];
     unsigned char* const wring = lds + IN_BYTES;
+    float* const par = (float*)(lds + IN_BYTES + C64_WRING * C64_TAP_BYTES);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -156,13 +136,7 @@ __global__ __launch_bounds__(256, 1) void conv_c64_kernel(C64Params p) {
         pcol[k] = (t - prow[k] * TWT) * 16;
     }
 
-    // every activation this kernel serves is  v >= 0 ? v : v * slope  (none: 1, ReLU: 0, LeakyReLU: param,
-    // PReLU: alpha) - branch-free, so the unrolled epilogue stays small enough for the instruction cache.
-    float slope0 = 1.f;
-    if (p.act == SRMI_ACT_RELU) slope0 = 0.f;
-    else if (p.act == SRMI_ACT_LRELU) slope0 = p.act_param;
-    else if (p.act == SRMI_ACT_PRELU && !p.alpha_pc) slope0 = p.alpha[0];
-    const bool slope_pc = p.act == SRMI_ACT_PRELU && p.alpha_pc;
+    c64_stage_params(par, p.epi, p.nchunk, tid, 256);
 
     // input tile written (own ds_writes: lgkmcnt; the staging loads' vmcnt(0) also retired taps 0..2)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -235,67 +209,14 @@ __global__ __launch_bounds__(256, 1) void conv_c64_kernel(C64Params p) {
             }
         }
 
-        // ---- epilogue: lane holds channels 16q .. 16q+15 of chunk s for pixel pl of each tile ----
-        float sc[16], sh[16], al[16];
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int co = c64_conv_channel(p.mode, s, 16 * q + e);
-            sc[e] = p.scale[co];
-            sh[e] = p.shift[co];
-            al[e] = slope_pc ? p.alpha[co] : slope0;
-        }
-        const int si = s >> 1, sj = s & 1;
-        if (!(p.dbg & 4))
-#pragma unroll
-        for (int k = 0; k < PT; ++k) {
-            const int oy = y0 + prow[k], ox = x0 + pcol[k] + pl;
-            if (oy >= p.H || ox >= p.W) continue;
-            size_t pix, cofs;
-            if (p.mode == 0) {
-                pix = ((size_t)n * p.H + oy) * p.W + ox;
-                cofs = (size_t)64 * s + 16 * q;
-            } else {
-                pix = ((size_t)n * 2 * p.H + 2 * oy + si) * (2 * p.W) + 2 * ox + sj;
-                cofs = (size_t)16 * q;
-            }
-            float v[16];
-#pragma unroll
-            for (int t = 0; t < 4; ++t)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int c = 4 * t + e;
-                    const float z = acc[k][t][e] * sc[c] + sh[c];
-                    v[c] = z >= 0.f ? z : z * al[c];
-                }
-            if (p.res) {
-                const int Cf = p.mode == 0 ? p.Cout : 64;
-                const u32x4* rp = (const u32x4*)(p.res + pix * Cf + cofs);
-                const u32x4 r0 = rp[0], r1 = rp[1];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[2 * e] += bf2f((bf16_t)(r0[e] & 0xffffu));
-                    v[2 * e + 1] += bf2f((bf16_t)(r0[e] >> 16));
-                    v[8 + 2 * e] += bf2f((bf16_t)(r1[e] & 0xffffu));
-                    v[8 + 2 * e + 1] += bf2f((bf16_t)(r1[e] >> 16));
-                }
-            }
-            u32x4 o0, o1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                o0[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
-                o1[e] = pack_bf2(v[8 + 2 * e], v[8 + 2 * e + 1]);
-            }
-            u32x4* op = (u32x4*)(p.y + pix * p.out_cs + p.out_co + cofs);
-            op[0] = o0;
-            op[1] = o1;
-        }
+        if (!(p.dbg & 4)) c64_epilogue<PT>(acc, par + s * 192, p.epi, s, n, y0, x0, prow, pcol, pl, q);
     }
 }
 
 // OIHW f32 -> bf16 MFMA A-fragment order:
 //   packed[(((s*18 + ks)*4 + t)*64 + lane)*8 + j] = W[co][ci][ky][kx]
 //   tap = ks>>1 (ky = tap/3, kx = tap%3), ci = (ks&1)*32 + 8*(lane>>4) + j,
-//   A-row r = lane&15 of channel tile t  <->  channel-in-chunk cl = 16*(r>>2) + 4*t + (r&3),
+//   A-row r = lane&15 of channel tile t  <->  channel-in-chunk cl = c64_row_to_cl(t, r),
 //   co = conv channel of (chunk s, cl) for the store mode.
 __global__ void c64_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout, int mode,
                                 size_t total) {
@@ -308,7 +229,7 @@ __global__ void c64_pack_kernel(const float* __restrict__ w, bf16_t* __restrict_
         const int ks = (int)(rest % 18);
         const int s = (int)(rest / 18);
         const int r = lane & 15, qq = lane >> 4;
-        const int cl = 16 * (r >> 2) + 4 * t + (r & 3);
+        const int cl = c64_row_to_cl(t, r);
         const int co = c64_conv_channel(mode, s, cl);
         const int ci = (ks & 1) * 32 + 8 * qq + j;
         const int tap = ks >> 1;
@@ -319,7 +240,7 @@ __global__ void c64_pack_kernel(const float* __restrict__ w, bf16_t* __restrict_
 bool c64_supported(const srmi_conv_desc& d) {
     if (d.compute != SRMI_COMPUTE_BF16) return false;
     if (d.kh != 3 || d.kw != 3 || d.stride != 1 || d.pad != 1 || d.Cin != 64) return false;
-    if (d.Cout % 64 != 0 || d.Cout <= 0) return false;
+    if (d.Cout % 64 != 0 || d.Cout <= 0 || d.Cout > 64 * C64_MAX_CHUNKS) return false;
     if (d.in_dtype != SRMI_BF16 || d.out_dtype != SRMI_BF16) return false;
     if (d.in_layout != SRMI_NHWC || d.out_layout != SRMI_NHWC) return false;
     if (d.shuffle != 1 && !(d.shuffle == 2 && d.Cout == 256)) return false;
@@ -359,12 +280,13 @@ int c64_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
         return SRMI_EUNSUPPORTED;
     }
     C64Params p;
-    p.x = (const bf16_t*)a.x; p.w = (const bf16_t*)a.w; p.scale = a.scale; p.shift = a.shift; p.alpha = a.alpha;
-    p.res = (const bf16_t*)a.residual; p.y = (bf16_t*)a.y;
-    p.N = d.N; p.H = d.H; p.W = d.W; p.Cout = d.Cout; p.nchunk = d.Cout / 64;
-    p.in_cs = g.in_cs; p.out_cs = g.out_cs; p.out_co = d.out_coffset;
-    p.act = d.act; p.act_param = d.act_param; p.alpha_pc = d.alpha_per_channel;
-    p.mode = c64_mode(d);
+    p.x = (const bf16_t*)a.x; p.w = (const bf16_t*)a.w;
+    p.epi.scale = a.scale; p.epi.shift = a.shift; p.epi.alpha = a.alpha;
+    p.epi.res = (const bf16_t*)a.residual; p.epi.y = (bf16_t*)a.y;
+    p.epi.H = d.H; p.epi.W = d.W; p.epi.Cout = d.Cout; p.epi.out_cs = g.out_cs; p.epi.out_co = d.out_coffset;
+    p.epi.mode = c64_mode(d);
+    p.epi.act = d.act; p.epi.act_param = d.act_param; p.epi.alpha_pc = d.alpha_per_channel;
+    p.N = d.N; p.H = d.H; p.W = d.W; p.nchunk = d.Cout / 64; p.in_cs = g.in_cs;
     { const char* e = getenv("SRMI_DBG"); p.dbg = e ? atoi(e) : 0; }
     if (d.N == 0 || d.H == 0 || d.W == 0) return SRMI_OK;
     // tile choice: 6 x 96 (9 pixel tiles per wave) when the image is wide enough to fill it,

@@ -164,3 +164,64 @@ def test_generic_kernel_bf16_storage(case):
 def test_c64_bf16_kernel(case):
     name = _run_case(Cin=64, k=3, io=torch.bfloat16, compute=L.COMPUTE_BF16, **case)
     assert name == "c64_bf16"
+
+
+@pytest.mark.parametrize("case", [
+    dict(N=2, H=10, W=12, Cout=3, act=L.ACT_TANH, out_layout=L.NCHW),          # last_conv (ragged tile)
+    dict(N=1, H=6, W=64, Cout=3, act=L.ACT_TANH, out_layout=L.NCHW),           # exactly one tile
+    dict(N=1, H=13, W=130, Cout=3, act=L.ACT_TANH, out_layout=L.NCHW),         # several tiles, ragged both ways
+    dict(N=1, H=7, W=20, Cout=1, act=L.ACT_NONE),                              # single channel, NHWC out
+    dict(N=1, H=7, W=20, Cout=4, act=L.ACT_SIGMOID, in_cs=160),                # channel-slice input
+])
+def test_c64_thin_kernel(case):
+    """64 -> <=4 channel conv (the HBM-bound last_conv): bf16 in, f32 out."""
+    g = _rng(3)
+    N, H, W, Cout = case["N"], case["H"], case["W"], case["Cout"]
+    act, in_cs = case["act"], case.get("in_cs", 0)
+    out_layout = case.get("out_layout", L.NHWC)
+    x = torch.from_numpy(g.uniform(-1, 1, (N, 64, H, W)).astype(np.float32)).bfloat16().float()
+    w = torch.from_numpy((g.standard_normal((Cout, 64, 3, 3)) / 24.0).astype(np.float32)).bfloat16().float()
+    scale = torch.from_numpy(g.uniform(0.5, 1.5, Cout).astype(np.float32))
+    shift = torch.from_numpy(g.uniform(-0.3, 0.3, Cout).astype(np.float32))
+    ref = _ref_fused(x, w, scale, shift, act, 0.0, None, None, 1, 1, 1, False)
+    desc = Fn.make_desc(N, H, W, 64, Cout, 3, in_dtype=L.BF16, out_dtype=L.F32, out_layout=out_layout,
+                        compute=L.COMPUTE_BF16, act=act, in_cstride=in_cs)
+    assert L.kernel_name(desc) == "c64_thin_bf16"
+    xd = torch.full((N, H, W, in_cs or 64), 7.0, dtype=torch.bfloat16)
+    xd[..., :64] = x.permute(0, 2, 3, 1).bfloat16()
+    wp = Fn.pack_weights(desc, w.to(DEV))
+    y = Fn.conv2d_fused(desc, xd.to(DEV), wp, scale.to(DEV), shift.to(DEV))
+    torch.cuda.synchronize()
+    got = y.cpu() if out_layout == L.NCHW else y.cpu().permute(0, 3, 1, 2)
+    err = (got.double() - ref).abs().max().item()
+    assert err <= 2e-5, err          # f32 accumulate of exact bf16 products: summation-order error only
+
+
+@pytest.mark.parametrize("case", [
+    dict(N=2, H=9, W=7, in_layout=L.NCHW),                  # tiny image, smaller than the 9x9 window reach
+    dict(N=1, H=13, W=100, in_layout=L.NCHW),               # big tile, ragged
+    dict(N=2, H=6, W=96, in_layout=L.NCHW),                 # exactly one big tile per image
+    dict(N=1, H=20, W=33, in_layout=L.NHWC),                # NHWC f32 input
+    dict(N=1, H=8, W=40, in_layout=L.NHWC, Cin=1),          # single-channel input (Y only)
+])
+def test_k9c3_kernel(case):
+    """conv01: 9x9, Cin<=3 -> 64, PReLU, f32 NCHW/NHWC in -> NHWC bf16 out."""
+    g = _rng(4)
+    N, H, W, Cin = case["N"], case["H"], case["W"], case.get("Cin", 3)
+    x = torch.from_numpy(g.uniform(-1, 1, (N, Cin, H, W)).astype(np.float32))
+    w = torch.from_numpy((g.standard_normal((64, Cin, 9, 9)) / np.sqrt(81.0 * Cin)).astype(np.float32))
+    scale = torch.from_numpy(g.uniform(0.5, 1.5, 64).astype(np.float32))
+    shift = torch.from_numpy(g.uniform(-0.3, 0.3, 64).astype(np.float32))
+    alpha = torch.tensor([0.25])
+    # the kernel rounds x and w to bf16 before the MFMA: so does the reference
+    ref = _ref_fused(x.bfloat16().float(), w.bfloat16().float(), scale, shift, L.ACT_PRELU, 0.0, alpha, None, 1, 4, 1, False)
+    desc = Fn.make_desc(N, H, W, Cin, 64, 9, in_dtype=L.F32, out_dtype=L.BF16, in_layout=case["in_layout"],
+                        compute=L.COMPUTE_BF16, act=L.ACT_PRELU)
+    assert L.kernel_name(desc) == "k9c3_bf16"
+    xd = (x if case["in_layout"] == L.NCHW else x.permute(0, 2, 3, 1).contiguous()).to(DEV)
+    wp = Fn.pack_weights(desc, w.to(DEV))
+    y = Fn.conv2d_fused(desc, xd, wp, scale.to(DEV), shift.to(DEV), alpha.to(DEV))
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    err = (got.double() - ref).abs()
+    assert torch.all(err <= 2.0 ** -8 * (ref.abs() + 1.0)), err.max().item()
