@@ -91,17 +91,21 @@ def per_kernel_times(gen, x, reps):
     plan.args[0].x = x.data_ptr()
     sr = torch.empty(plan.sr_shape, dtype=torch.float32, device=x.device)
     plan.args[n - 1].y = sr.data_ptr()
-    tot = np.zeros(n)
+    units = plan.launches                       # (label, first conv index, convs in the launch)
+    tot = np.zeros(len(units))
     st = Fn.stream_ptr()
     for _ in range(reps):
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(units) + 1)]
         ev[0].record()
-        for i in range(n):
-            L.check(lib.srmi_conv2d_fwd(C.byref(plan.args[i]), st))
-            ev[i + 1].record()
+        for u, (label, i, cnt) in enumerate(units):
+            if cnt == 2:
+                L.check(lib.srmi_resblock_fwd(C.byref(plan.args[i]), C.byref(plan.args[i + 1]), st))
+            else:
+                L.check(lib.srmi_conv2d_fwd(C.byref(plan.args[i]), st))
+            ev[u + 1].record()
         torch.cuda.synchronize()
-        tot += np.array([ev[i].elapsed_time(ev[i + 1]) for i in range(n)])
-    return plan, tot / reps   # ms per launch
+        tot += np.array([ev[u].elapsed_time(ev[u + 1]) for u in range(len(units))])
+    return plan, units, tot / reps   # ms per launch
 
 
 def cpu_baseline(threads, sd, x):
@@ -175,22 +179,25 @@ def main():
     if rank == 0:
         # ---- roofline of the dominant kernel (HIP events, same process, same data) -------------
         with torch.no_grad():
-            plan, kms = per_kernel_times(gen, x, reps=max(5, min(20, args.steps)))
-        dom = "c64_bf16" if args.compute == "bf16" else "generic_f32"
-        idx = [i for i, k in enumerate(plan.kernels) if k == dom]
-        flops = sum(conv_flops(plan.args[i].d) for i in idx)
-        t_dom = float(sum(kms[i] for i in idx)) * 1e-3
+            plan, units, kms = per_kernel_times(gen, x, reps=max(5, min(20, args.steps)))
+        # dominant kernel family = the 64-channel bf16 MFMA implicit-GEMM kernels (conv_c64_kernel and its
+        # two-conv fusion resblock_c64_kernel): 98 % of the network's FLOPs
+        dom = ("c64_bf16", "resblock_bf16") if args.compute == "bf16" else ("generic_f32",)
         peak = PEAK_BF16_TFLOPS if args.compute == "bf16" else PEAK_F32_MFMA_TFLOPS
-        achieved = flops / t_dom / 1e12
-        per_layer = {}
-        for i, k in enumerate(plan.kernels):
+        per_layer, flops, t_dom, n_dom = {}, 0.0, 0.0, 0
+        for u, (label, i, cnt) in enumerate(units):
             d = plan.args[i].d
-            key = f"{k}:{d.Cin}->{d.Cout}@{d.H}x{d.W}k{d.kh}"
+            fl = sum(conv_flops(plan.args[i + c].d) for c in range(cnt))
+            key = f"{label}:{d.Cin}->{plan.args[i + cnt - 1].d.Cout}@{d.H}x{d.W}k{d.kh}"
             e = per_layer.setdefault(key, [0, 0.0, 0.0])
-            e[0] += 1; e[1] += kms[i]; e[2] += conv_flops(d)
+            e[0] += 1; e[1] += kms[u]; e[2] += fl
+            if label in dom:
+                flops += fl; t_dom += kms[u] * 1e-3; n_dom += 1
+        achieved = flops / t_dom / 1e12
         layers = {k: {"launches": v[0], "ms": round(v[1], 4), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
                   for k, v in per_layer.items()}
-        roofline = {"bound": "mfma", "kernel": "conv_c64_kernel" if dom == "c64_bf16" else "conv_generic_kernel",
+        idx = list(range(n_dom))
+        roofline = {"bound": "mfma", "kernel": "conv_c64_kernel + resblock_c64_kernel" if args.compute == "bf16" else "conv_generic_kernel",
                     "launches_per_step": len(idx), "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": None,
                     "avg_launch_us": round(t_dom / len(idx) * 1e6, 2),

@@ -97,7 +97,16 @@ typedef struct srmi_conv_args {
     const float* alpha;    /* PReLU slope(s), f32, device memory (read in-kernel: no host sync) */
     const void* residual;  /* NULL or a dense tensor shaped like the final output */
     void* y;               /* output */
+    int32_t flags;         /* SRMI_CONV_* bits, 0 = none */
+    int32_t reserved;      /* must be 0 */
 } srmi_conv_args;
+
+/* srmi_conv_args.flags */
+#define SRMI_CONV_FUSE_NEXT 1 /* inside srmi_conv2d_fwd_seq: y is consumed ONLY by the next conv of the
+                                 sequence (whose x is this y), so the pair may run as one fused launch
+                                 that never writes y (the ResBlock conv-BN-act-conv-BN-add, P/ops.py:45-48).
+                                 y must still be a valid scratch buffer: shapes no fused kernel serves
+                                 run as two launches. */
 
 /* library version (SRMI_VERSION of the build). */
 int srmi_version(void);
@@ -122,6 +131,15 @@ int srmi_conv2d_fwd(const srmi_conv_args* a, void* stream);
 /* n fused convs enqueued back to back on `stream` from native code (one FFI crossing per forward
  * of `Generator`, P/srgan_model.py:27-39: 37 convs). */
 int srmi_conv2d_fwd_seq(const srmi_conv_args* a, int32_t n, void* stream);
+
+/* ResBlock in one launch: y = residual + affine2(conv2(act(affine1(conv1(x))))); the intermediate stays
+ * in LDS.  conv2->x is ignored; conv2->y must not alias conv1->x.  Returns SRMI_EUNSUPPORTED when the
+ * pair is not a fusable shape (3x3, 64->64->64, NHWC bf16, SRMI_COMPUTE_BF16). Replaces `ResBlock.forward`
+ * (P/ops.py:45-48). */
+int srmi_resblock_fwd(const srmi_conv_args* conv1, const srmi_conv_args* conv2, void* stream);
+
+/* 1 if srmi_conv2d_fwd_seq would run (conv1 flagged SRMI_CONV_FUSE_NEXT, conv2) as one fused launch, else 0. */
+int srmi_conv2d_can_fuse(const srmi_conv_args* conv1, const srmi_conv_args* conv2);
 
 /* dense tensor re-layout / cast: src (N,C,H,W logical) in (src_layout, src_dtype) -> dst.
  * Replaces the implicit NCHW contract at the module edge (P/dataset.py:46-47, P/mode.py:396-400). */

@@ -162,9 +162,45 @@ int srmi_conv2d_pack_weights(const srmi_conv_desc* d, const float* w_oihw, void*
 
 int srmi_conv2d_fwd(const srmi_conv_args* a, void* stream) { return conv_fwd_one(a, (hipStream_t)stream); }
 
+static bool can_fuse_pair(const srmi_conv_args* a1, const srmi_conv_args* a2) {
+    ConvGeom g;
+    if (conv_geom(a1->d, &g) || conv_geom(a2->d, &g)) return false;
+    if (!resblock_supported(a1->d, a2->d)) return false;
+    if (a1->residual || !a1->x || !a1->w || !a2->w || !a2->y || !a1->scale || !a1->shift || !a2->scale || !a2->shift)
+        return false;
+    if ((a1->d.act == SRMI_ACT_PRELU && !a1->alpha) || (a2->d.act == SRMI_ACT_PRELU && !a2->alpha)) return false;
+    if (a2->x && a2->x != a1->y) return false;
+    if (a2->y == a1->x) return false;
+    return true;
+}
+
+int srmi_conv2d_can_fuse(const srmi_conv_args* conv1, const srmi_conv_args* conv2) {
+    return (conv1 && conv2 && can_fuse_pair(conv1, conv2)) ? 1 : 0;
+}
+
+int srmi_resblock_fwd(const srmi_conv_args* conv1, const srmi_conv_args* conv2, void* stream) {
+    if (!conv1 || !conv2) { set_error("resblock: NULL args"); return SRMI_EINVAL; }
+    ConvGeom g;
+    int rc = conv_geom(conv1->d, &g);
+    if (rc) return rc;
+    rc = conv_geom(conv2->d, &g);
+    if (rc) return rc;
+    if (!can_fuse_pair(conv1, conv2)) {
+        set_error("resblock: not a fusable pair (need 3x3 64->64->64 NHWC bf16, SRMI_COMPUTE_BF16, y != x)");
+        return SRMI_EUNSUPPORTED;
+    }
+    return resblock_launch(*conv1, *conv2, (hipStream_t)stream);
+}
+
 int srmi_conv2d_fwd_seq(const srmi_conv_args* a, int32_t n, void* stream) {
     if (n < 0 || (n > 0 && !a)) { set_error("fwd_seq: bad arguments"); return SRMI_EINVAL; }
     for (int32_t i = 0; i < n; ++i) {
+        if ((a[i].flags & SRMI_CONV_FUSE_NEXT) && i + 1 < n && can_fuse_pair(a + i, a + i + 1)) {
+            int rc = resblock_launch(a[i], a[i + 1], (hipStream_t)stream);
+            if (rc) return rc;
+            ++i;
+            continue;
+        }
         int rc = conv_fwd_one(a + i, (hipStream_t)stream);
         if (rc) return rc;
     }

@@ -57,10 +57,12 @@ __device__ __forceinline__ void c64_stage_params(float* par, const C64Epi& e, in
 // Fused epilogue of one 64-channel chunk: scale/shift -> slope activation -> +residual -> bf16 store
 // (plain NHWC channel slice, or one sub-pixel of a PixelShuffle(2)/depth_to_space(2) output).
 // acc[k][t][e] = channel 32*(t>>1) + 8q + 4*(t&1) + e of pixel pl of this wave's pixel tile k.
-template <int PT>
+// PRE: the residual of every pixel tile is already in registers (rpre), e.g. taken from an LDS-resident
+// input tile by the fused ResBlock kernel; otherwise it is loaded from o.res (if any).
+template <int PT, bool PRE = false>
 __device__ __forceinline__ void c64_epilogue(const f32x4 (&acc)[PT][4], const float* par_s, const C64Epi& o, int s,
                                              int n, int y0, int x0, const int (&prow)[PT], const int (&pcol)[PT],
-                                             int pl, int q) {
+                                             int pl, int q, const u32x4 (*rpre)[2] = nullptr) {
     float sc[16], sh[16], sl[16];
 #pragma unroll
     for (int hi = 0; hi < 2; ++hi)
@@ -82,15 +84,23 @@ __device__ __forceinline__ void c64_epilogue(const f32x4 (&acc)[PT][4], const fl
     const int cbase = (o.mode == C64_PLAIN ? 64 * s : 0) + 8 * q;
     size_t pix[PT];
     bool ok[PT];
+    // opaque zero: keeps hipcc from hoisting the address arithmetic above the K loop (it would be spilled
+    // to scratch there: the loops run at the 512-register limit)
+    int opaque0;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));
 #pragma unroll
     for (int k = 0; k < PT; ++k) {
-        const int oy = y0 + prow[k], ox = x0 + pcol[k] + pl;
+        const int oy = y0 + prow[k], ox = x0 + pcol[k] + pl + opaque0;
         ok[k] = oy < o.H && ox < o.W;
         pix[k] = o.mode == C64_PLAIN ? ((size_t)n * o.H + oy) * o.W + ox
                                      : ((size_t)n * 2 * o.H + 2 * oy + si) * (2 * o.W) + 2 * ox + sj;
     }
     u32x4 r[PT][2];
-    if (o.res) {   // all residual loads in flight before the first use
+    const bool have_res = PRE || o.res != nullptr;
+    if constexpr (PRE) {
+#pragma unroll
+        for (int k = 0; k < PT; ++k) { r[k][0] = rpre[k][0]; r[k][1] = rpre[k][1]; }
+    } else if (o.res) {   // all residual loads in flight before the first use
 #pragma unroll
         for (int k = 0; k < PT; ++k) {
             r[k][0] = (u32x4){0u, 0u, 0u, 0u};
@@ -113,7 +123,7 @@ __device__ __forceinline__ void c64_epilogue(const f32x4 (&acc)[PT][4], const fl
                 const float z = acc[k][t][e] * sc[c] + sh[c];
                 v[c] = z >= 0.f ? z : z * sl[c];
             }
-        if (o.res) {
+        if (have_res) {
 #pragma unroll
             for (int hi = 0; hi < 2; ++hi)
 #pragma unroll

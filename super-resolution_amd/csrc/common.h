@@ -21,8 +21,12 @@ typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float bf2f(bf16_t u) { return __builtin_bit_cast(float, (unsigned)u << 16); }
 // round-to-nearest-even, NaN stays NaN (plain cast -> v_cvt_pk_bf16_f32 on gfx950)
 __device__ __forceinline__ bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+// two f32 -> packed bf16x2 (RNE) in ONE instruction; hipcc has no builtin for it and emits
+// 2 cvt + shift + or for the scalar form (the epilogues are VALU-issue-bound at one wave per SIMD)
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
-    return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+    unsigned r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
 }
 
 __device__ __forceinline__ float apply_act(float v, int act, float param, float alpha) {
@@ -77,5 +81,9 @@ bool k9c3_supported(const srmi_conv_desc& d);
 size_t k9c3_packed_bytes(const srmi_conv_desc& d);
 int k9c3_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s);
 int k9c3_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s);
+
+// fused ResBlock (conv_resblock_bf16.hip)
+bool resblock_supported(const srmi_conv_desc& d1, const srmi_conv_desc& d2);
+int resblock_launch(const srmi_conv_args& a1, const srmi_conv_args& a2, hipStream_t s);
 
 }  // namespace srmi

@@ -1,0 +1,330 @@
+// Fused ResBlock: y = x + affine2(conv3x3(act(affine1(conv3x3(x)))))  for 64 channels, NHWC bf16,
+// in ONE launch (P/ops.py:37-48: conv-BN-PReLU, conv-BN, `res += x`; eval-mode BN folded into affine).
+//
+// Why: between two launches every activation goes through the memory side (per-XCD L2s are written
+// back at a kernel boundary), which is bound at ~6 TB/s; an unfused 64->64 conv moves 64 MB per
+// 10.9 GFLOP and is memory-bound.  Keeping the intermediate tensor T in LDS halves the traffic of
+// the network's 32 body convs at the price of re-computing T on a one-pixel halo ring.
+//
+//   LDS (one array, 157 KiB for the 6 x 96 tile):
+//     [ x halo tile (TH+4) x (TW+4) px, later overwritten by T (TH+2) x (TW+2) px | weight ring | params ]
+//   phase 1  conv1 on the (TH+2) x (TW+2) T region, FLATTENED into 16-pixel MFMA tiles (49 tiles for
+//            8 x 98 pixels, 13 per wave) so the halo ring costs 1.44x, not 1.56x, of a tile's MFMAs;
+//   phase 2  barrier; T = act(affine1(acc)) -> bf16, zero outside the image (conv2's zero padding),
+//            written over the x tile in the same swizzled layout; barrier;
+//   phase 3  conv2 from T exactly like conv_c64_kernel; epilogue adds x (re-read from L2/MALL) and stores.
+//            (Keeping the 72 residual registers per lane across phases 2-3 was tried: hipcc spills them to
+//            scratch at the 512-register limit, which costs what the re-read costs.)
+//   Weights: both convs' packed A fragments stream through a 4-slot x 4 KiB LDS-DMA ring, one K-step
+//   (4 fragments) per slot, three steps ahead, across the phase boundary; hand-off per step =
+//   counted vmcnt + s_barrier (slot j-1 is re-filled at barrier j: its readers are provably done).
+#include <stdlib.h>
+
+#include "c64_common.h"
+
+namespace srmi {
+
+struct ResBlockParams {
+    const bf16_t* x; const bf16_t* w1; const bf16_t* w2;
+    C64Epi epi1;   // scale/shift/act of conv1 (res, y unused)
+    C64Epi epi2;   // scale/shift/act of conv2, residual, output
+    int N, H, W, in_cs;
+    int tiles_x, tiles_y;
+    int dbg;  // ablation (SRMI_DBG env, investigation only): 1 skip staging, 2 skip conv1 K loop, 8 skip conv2 K loop, 4 skip epilogue, 16 skip T write
+};
+
+constexpr int RB_SLOTS = 4;
+constexpr int RB_STEP_BYTES = 4096;   // one K-step: 4 channel tiles x 64 lanes x 16 B
+
+template <int TH, int TWT>
+__global__ __launch_bounds__(256, 1) void resblock_c64_kernel(ResBlockParams p) {
+    constexpr int TW = TWT * 16;
+    constexpr int XR = TH + 4, XC = TW + 4;          // x halo tile
+    constexpr int TR = TH + 2, TC = TW + 2;          // T region
+    constexpr int ROWP = (XC + 15) / 16 * 16;        // LDS row pitch in pixels (multiple of 16)
+    constexpr int IN_BYTES = XR * ROWP * 128;
+    constexpr int NT1 = (TR * TC + 15) / 16;         // flattened 16-pixel tiles of the T region
+    constexpr int PT1 = (NT1 + 3) / 4;
+    constexpr int NPT2 = TH * TWT;
+    static_assert(NPT2 % 4 == 0, "pixel tiles must split evenly over 4 waves");
+    constexpr int PT2 = NPT2 / 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[IN_BYTES + RB_SLOTS * RB_STEP_BYTES + 2 * 768];
+    unsigned char* const wring = lds + IN_BYTES;
+    float* const par = (float*)(lds + IN_BYTES + RB_SLOTS * RB_STEP_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 15, q = lane >> 4;
+
+    int b = blockIdx.x;
+    const int tx = b % p.tiles_x; b /= p.tiles_x;
+    const int ty = b % p.tiles_y;
+    const int n = b / p.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+
+    // ---- weight stream: K-step g of 36 (conv1: 0..17, conv2: 18..35); wave w copies KiB w of each ----
+    const unsigned wring_lds = (unsigned)(uintptr_t)(lptr_t)wring;
+    auto issue_step = [&](int g) {
+        const unsigned char* base = (const unsigned char*)(g < 18 ? p.w1 : p.w2);
+        const unsigned char* src = base + (size_t)(g < 18 ? g : g - 18) * RB_STEP_BYTES + wave * 1024 + lane * 16;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(
+            wring_lds + (unsigned)((g & (RB_SLOTS - 1)) * RB_STEP_BYTES + wave * 1024));
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(src), "s"(dst)
+            : "memory");
+    };
+    issue_step(0);
+    issue_step(1);
+    issue_step(2);
+
+    // ---- stage the x halo tile (2-pixel ring) ----------------------------------------------------
+    if (!(p.dbg & 1)) {
+        constexpr int NCH = XR * XC * 8;
+        constexpr int NIT = (NCH + 255) / 256;
+        const bf16_t* xin = p.x + (size_t)n * p.H * p.W * p.in_cs;
+        u32x4 v[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = min(tid + it * 256, NCH - 1);
+            const int pp = idx >> 3, ch = idx & 7;
+            const int row = pp / XC, col = pp - row * XC;
+            const int gy = min(max(y0 - 2 + row, 0), p.H - 1), gx = min(max(x0 - 2 + col, 0), p.W - 1);
+            v[it] = *(const u32x4*)(xin + ((size_t)gy * p.W + gx) * p.in_cs + ch * 8);
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int idx = tid + it * 256;
+            const int pp = idx >> 3, ch = idx & 7;
+            const int row = pp / XC, col = pp - row * XC;
+            const int gy = y0 - 2 + row, gx = x0 - 2 + col;
+            u32x4 z = v[it];
+            if (!(gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)) z = (u32x4){0u, 0u, 0u, 0u};
+            const int P = row * ROWP + col;
+            if (idx < NCH) *(u32x4*)(lds + P * 128 + ((ch ^ ((P >> 1) & 7)) << 4)) = z;
+        }
+    }
+    c64_stage_params(par, p.epi1, 1, tid, 256);
+    c64_stage_params(par + 192, p.epi2, 1, tid, 256);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // also retires weight steps 0..2
+    __builtin_amdgcn_s_barrier();
+
+    // one K-step hand-off: step g+1 landed (own copy: counted vmcnt, others': barrier); slot of step g-1
+    // is free (its fragments were consumed by the MFMAs of step g-1, which every wave has issued).
+    auto handoff = [&](int g) {
+        if (g + 2 < 36) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (g + 3 < 36) issue_step(g + 3);
+    };
+
+    // ================= phase 1: conv1 over the flattened T region =================================
+    int boff1[PT1][3];
+#pragma unroll
+    for (int k = 0; k < PT1; ++k) {
+        const int pix = min((wave * PT1 + k) * 16 + pl, TR * TC - 1);   // padding tiles recompute the last pixel
+        const int ti = pix / TC, tj = pix - ti * TC;
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int P = ti * ROWP + tj + dx;
+            boff1[k][dx] = P * 128 + ((q ^ ((P >> 1) & 7)) << 4);
+        }
+    }
+    {
+        f32x4 acc[PT1][4];
+#pragma unroll
+        for (int k = 0; k < PT1; ++k)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[k][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bf16x8 afr[2][4], bfr[2][PT1];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) afr[0][t] = *(const bf16x8*)(wring + lane * 16 + t * 1024);
+#pragma unroll
+        for (int k = 0; k < PT1; ++k) bfr[0][k] = *(const bf16x8*)(lds + boff1[k][0]);
+        if (!(p.dbg & 2))
+#pragma unroll
+        for (int j = 0; j < 18; ++j) {
+            handoff(j);
+            {   // prefetch the fragments of global step j+1 (step 18 = first step of conv2: weights only)
+                const unsigned char* wslot = wring + ((j + 1) & (RB_SLOTS - 1)) * RB_STEP_BYTES + lane * 16;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) afr[(j + 1) & 1][t] = *(const bf16x8*)(wslot + t * 1024);
+                if (j + 1 < 18) {
+                    const int tapn = (j + 1) >> 1, halfn = (j + 1) & 1;
+                    const int dyn = tapn / 3, dxn = tapn - 3 * dyn;
+#pragma unroll
+                    for (int k = 0; k < PT1; ++k)
+                        bfr[(j + 1) & 1][k] =
+                            *(const bf16x8*)(lds + ((boff1[k][dxn] ^ (halfn << 6)) + dyn * (ROWP * 128)));
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < PT1; ++k)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[j & 1][t], bfr[j & 1][k], acc[k][t], 0, 0, 0);
+            if (j + 1 < 18) sched_interleave<0, 4 + PT1, 4 * PT1>();
+        }
+
+        // ---- phase 2: T = act(affine1(acc)) as bf16 over the x tile (zero outside the image) ----
+        float sc[16], sh[16], sl[16];
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+            for (int v4 = 0; v4 < 2; ++v4) {
+                const int c = 32 * hi + 8 * q + 4 * v4;
+                const f32x4 a = *(const f32x4*)(par + c);
+                const f32x4 bsh = *(const f32x4*)(par + 64 + c);
+                const f32x4 csl = *(const f32x4*)(par + 128 + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    sc[8 * hi + 4 * v4 + e] = a[e];
+                    sh[8 * hi + 4 * v4 + e] = bsh[e];
+                    sl[8 * hi + 4 * v4 + e] = csl[e];
+                }
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();           // every wave has finished reading the x tile
+        // opaque zero: keeps hipcc from hoisting this phase's address arithmetic above the K loop, where it
+        // would be spilled to scratch (the loop runs at the 512-register limit)
+        int opaque0;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));
+        if (!(p.dbg & 16))
+#pragma unroll
+        for (int k = 0; k < PT1; ++k) {
+            const int pix = min((wave * PT1 + k) * 16 + pl + opaque0, TR * TC - 1);
+            const int ti = pix / TC, tj = pix - ti * TC;
+            const int gy = y0 - 1 + ti, gx = x0 - 1 + tj;
+            const unsigned keep = (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? 0xffffffffu : 0u;
+            float v[16];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 4 * t + e;
+                    const float z = acc[k][t][e] * sc[c] + sh[c];
+                    v[c] = z >= 0.f ? z : z * sl[c];
+                }
+            u32x4 o0, o1;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {      // zero padding of conv2: select on the packed words
+                o0[e] = pack_bf2(v[2 * e], v[2 * e + 1]) & keep;
+                o1[e] = pack_bf2(v[8 + 2 * e], v[8 + 2 * e + 1]) & keep;
+            }
+            if ((wave * PT1 + k) * 16 + pl + opaque0 < TR * TC) {
+                const int P = ti * ROWP + tj;
+                const int sw = (P >> 1) & 7;
+                *(u32x4*)(lds + P * 128 + ((q ^ sw) << 4)) = o0;          // channels 8q .. 8q+7   = chunk q
+                *(u32x4*)(lds + P * 128 + (((4 + q) ^ sw) << 4)) = o1;    // channels 32+8q ..     = chunk 4+q
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();           // T complete
+        // (the first weight fragments of conv2 were prefetched into afr[0] during step 17: 18 & 1 == 0)
+        // ================= phase 3: conv2 from T ==================================================
+        int prow[PT2], pcol[PT2];
+        int boff2[PT2][3];
+#pragma unroll
+        for (int k = 0; k < PT2; ++k) {
+            const int t = wave * PT2 + k;
+            prow[k] = t / TWT;
+            pcol[k] = (t - prow[k] * TWT) * 16;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int P = prow[k] * ROWP + pcol[k] + pl + dx;
+                boff2[k][dx] = P * 128 + ((q ^ ((P >> 1) & 7)) << 4);
+            }
+        }
+        f32x4 acc2[PT2][4];
+#pragma unroll
+        for (int k = 0; k < PT2; ++k)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc2[k][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        bf16x8 bfr2[2][PT2];
+#pragma unroll
+        for (int k = 0; k < PT2; ++k) bfr2[0][k] = *(const bf16x8*)(lds + boff2[k][0]);
+        if (!(p.dbg & 8))
+#pragma unroll
+        for (int j = 0; j < 18; ++j) {
+            const int g = 18 + j;
+            if (g + 1 < 36) {
+                handoff(g);
+                const unsigned char* wslot = wring + ((g + 1) & (RB_SLOTS - 1)) * RB_STEP_BYTES + lane * 16;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) afr[(j + 1) & 1][t] = *(const bf16x8*)(wslot + t * 1024);
+                const int tapn = (j + 1) >> 1, halfn = (j + 1) & 1;
+                const int dyn = tapn / 3, dxn = tapn - 3 * dyn;
+#pragma unroll
+                for (int k = 0; k < PT2; ++k)
+                    bfr2[(j + 1) & 1][k] =
+                        *(const bf16x8*)(lds + ((boff2[k][dxn] ^ (halfn << 6)) + dyn * (ROWP * 128)));
+            }
+#pragma unroll
+            for (int k = 0; k < PT2; ++k)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc2[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[j & 1][t], bfr2[j & 1][k], acc2[k][t], 0, 0, 0);
+            if (j + 1 < 18) sched_interleave<0, 4 + PT2, 4 * PT2>();
+        }
+        if (!(p.dbg & 4)) c64_epilogue<PT2>(acc2, par + 192, p.epi2, 0, n, y0, x0, prow, pcol, pl, q);
+    }
+}
+
+bool resblock_supported(const srmi_conv_desc& d1, const srmi_conv_desc& d2) {
+    if (!c64_supported(d1) || !c64_supported(d2)) return false;
+    if (d1.Cout != 64 || d2.Cout != 64 || d1.shuffle != 1 || d2.shuffle != 1) return false;
+    if (d1.N != d2.N || d1.H != d2.H || d1.W != d2.W) return false;
+    if (d1.out_cstride && d1.out_cstride != 64) return false;   // T must be a plain 64-channel tensor
+    if (d1.out_coffset || (d2.in_cstride && d2.in_cstride != 64)) return false;
+    return true;
+}
+
+int resblock_launch(const srmi_conv_args& a1, const srmi_conv_args& a2, hipStream_t s) {
+    const srmi_conv_desc& d1 = a1.d;
+    const srmi_conv_desc& d2 = a2.d;
+    if (((uintptr_t)a1.x | (uintptr_t)a1.w | (uintptr_t)a2.w | (uintptr_t)a2.y | (uintptr_t)a2.residual) & 15) {
+        set_error("resblock_bf16: buffers must be 16-byte aligned");
+        return SRMI_EINVAL;
+    }
+    if (a1.residual) { set_error("resblock_bf16: conv1 cannot take a residual"); return SRMI_EUNSUPPORTED; }
+    if (a2.residual && d2.res_dtype != SRMI_BF16) { set_error("resblock_bf16: residual must be bf16"); return SRMI_EUNSUPPORTED; }
+    if (a2.y == a1.x) {
+        set_error("resblock_bf16: output must not alias the input (neighbouring tiles read its halo)");
+        return SRMI_EINVAL;
+    }
+    ResBlockParams p;
+    p.x = (const bf16_t*)a1.x; p.w1 = (const bf16_t*)a1.w; p.w2 = (const bf16_t*)a2.w;
+    p.epi1.scale = a1.scale; p.epi1.shift = a1.shift; p.epi1.alpha = a1.alpha; p.epi1.res = nullptr; p.epi1.y = nullptr;
+    p.epi1.H = d1.H; p.epi1.W = d1.W; p.epi1.Cout = 64; p.epi1.out_cs = 64; p.epi1.out_co = 0; p.epi1.mode = C64_PLAIN;
+    p.epi1.act = d1.act; p.epi1.act_param = d1.act_param; p.epi1.alpha_pc = d1.alpha_per_channel;
+    p.epi2.scale = a2.scale; p.epi2.shift = a2.shift; p.epi2.alpha = a2.alpha;
+    p.epi2.res = (const bf16_t*)a2.residual; p.epi2.y = (bf16_t*)a2.y;
+    p.epi2.H = d2.H; p.epi2.W = d2.W; p.epi2.Cout = 64;
+    p.epi2.out_cs = d2.out_cstride ? d2.out_cstride : 64; p.epi2.out_co = d2.out_coffset; p.epi2.mode = C64_PLAIN;
+    p.epi2.act = d2.act; p.epi2.act_param = d2.act_param; p.epi2.alpha_pc = d2.alpha_per_channel;
+    p.N = d1.N; p.H = d1.H; p.W = d1.W; p.in_cs = d1.in_cstride ? d1.in_cstride : 64;
+    { const char* e = getenv("SRMI_DBG"); p.dbg = e ? atoi(e) : 0; }
+    if (d1.N == 0 || d1.H == 0 || d1.W == 0) return SRMI_OK;
+    const bool big = d1.W > 64 && d1.H >= 6;
+    if (big) {
+        p.tiles_x = (d1.W + 95) / 96; p.tiles_y = (d1.H + 5) / 6;
+        const long long nb = (long long)d1.N * p.tiles_x * p.tiles_y;
+        if (nb > 0x7fffffffLL) { set_error("resblock_bf16: grid too large"); return SRMI_EINVAL; }
+        hipLaunchKernelGGL((resblock_c64_kernel<6, 6>), dim3((unsigned)nb), dim3(256), 0, s, p);
+    } else {
+        p.tiles_x = (d1.W + 31) / 32; p.tiles_y = (d1.H + 3) / 4;
+        const long long nb = (long long)d1.N * p.tiles_x * p.tiles_y;
+        if (nb > 0x7fffffffLL) { set_error("resblock_bf16: grid too large"); return SRMI_EINVAL; }
+        hipLaunchKernelGGL((resblock_c64_kernel<4, 2>), dim3((unsigned)nb), dim3(256), 0, s, p);
+    }
+    return hip_check(hipGetLastError(), "resblock_c64_kernel");
+}
+
+}  // namespace srmi

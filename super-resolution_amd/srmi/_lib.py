@@ -51,7 +51,11 @@ class ConvArgs(C.Structure):
         ("x", C.c_void_p), ("w", C.c_void_p),
         ("scale", C.c_void_p), ("shift", C.c_void_p), ("alpha", C.c_void_p),
         ("residual", C.c_void_p), ("y", C.c_void_p),
+        ("flags", C.c_int32), ("reserved", C.c_int32),
     ]
+
+
+CONV_FUSE_NEXT = 1
 
 
 # every symbol include/srmi.h declares: name -> (restype, argtypes)
@@ -63,6 +67,8 @@ SYMBOLS = {
     "srmi_conv2d_pack_weights": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
     "srmi_conv2d_fwd": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "srmi_conv2d_fwd_seq": (C.c_int, [C.POINTER(ConvArgs), C.c_int32, C.c_void_p]),
+    "srmi_conv2d_can_fuse": (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs)]),
+    "srmi_resblock_fwd": (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), C.c_void_p]),
     "srmi_layout_convert": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
 }

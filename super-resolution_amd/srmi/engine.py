@@ -58,7 +58,7 @@ class _Seq:
         return t
 
     def add(self, block_or_parts, x, y, N, H, W, *, residual=None, shuffle=1, in_layout=L.NHWC, out_layout=L.NHWC,
-            in_dtype=None, out_dtype=None, weight=None, k=None, stride=None, cin=None, cout=None):
+            in_dtype=None, out_dtype=None, weight=None, k=None, stride=None, cin=None, cout=None, fuse_next=False):
         c2d, bn, act = block_or_parts if isinstance(block_or_parts, tuple) else conv_parts(block_or_parts)
         if bn is not None and bn.training:
             raise NotImplementedError("srmi: train-mode BatchNorm is not part of the inference plan")
@@ -82,16 +82,31 @@ class _Seq:
             if alpha.dtype != torch.float32:
                 raise TypeError("PReLU weight must be float32")
         self.keep += [wp, scale, shift]
-        self.layers.append((desc, x, wp, scale, shift, alpha, residual, y))
+        self.layers.append((desc, x, wp, scale, shift, alpha, residual, y, fuse_next))
         self.kernels.append(L.kernel_name(desc))
         return y
 
     def finish(self):
         n = len(self.layers)
         arr = (L.ConvArgs * n)()
-        for i, (desc, x, wp, scale, shift, alpha, residual, y) in enumerate(self.layers):
+        for i, (desc, x, wp, scale, shift, alpha, residual, y, fuse_next) in enumerate(self.layers):
             Fn.fill_args(arr[i], desc, x if x is not None else 0, wp, scale, shift, alpha, residual, y)
+            arr[i].flags = L.CONV_FUSE_NEXT if fuse_next else 0
         return arr, n
+
+    @staticmethod
+    def launches(arr, n, kernels):
+        """[(label, first index, count)]: what srmi_conv2d_fwd_seq will actually launch."""
+        lib = L.load()
+        out, i = [], 0
+        while i < n:
+            if (arr[i].flags & L.CONV_FUSE_NEXT) and i + 1 < n and lib.srmi_conv2d_can_fuse(C.byref(arr[i]), C.byref(arr[i + 1])):
+                out.append(("resblock_bf16", i, 2))
+                i += 2
+            else:
+                out.append((kernels[i], i, 1))
+                i += 1
+        return out
 
 
 class GeneratorPlan:
@@ -108,11 +123,14 @@ class GeneratorPlan:
         s.add(gen.conv01, None, skip, N, H, W, in_layout=L.NCHW, in_dtype=L.F32)
         cur = skip
         tmp = s.buf(N, H, W, nf)
-        run = s.buf(N, H, W, nf)
-        for blk in gen.body:                       # ResBlock, P/ops.py:45-48
-            s.add(blk.body[0], cur, tmp, N, H, W)
-            s.add(blk.body[1], tmp, run, N, H, W, residual=cur)   # in place on `run` after block 0
-            cur = run
+        ping = [s.buf(N, H, W, nf), s.buf(N, H, W, nf)]
+        for i, blk in enumerate(gen.body):         # ResBlock, P/ops.py:45-48
+            # the pair may run as ONE fused launch (tmp never written); ping-pong outputs because the
+            # fused kernel's neighbours read the input's halo while this tile's output is stored
+            out = ping[i & 1]
+            s.add(blk.body[0], cur, tmp, N, H, W, fuse_next=True)
+            s.add(blk.body[1], tmp, out, N, H, W, residual=cur)
+            cur = out
         feat = s.buf(N, H, W, nf)
         s.add(gen.conv02, cur, feat, N, H, W, residual=skip)      # P/srgan_model.py:33-34
         x, h, w = feat, H, W
@@ -132,6 +150,8 @@ class GeneratorPlan:
         self.args, self.n = s.finish()
         self.kernels = s.kernels
         self._seq = s
+        self.args[0].x = skip.data_ptr()          # placeholder so fusability can be queried before run()
+        self.launches = _Seq.launches(self.args, self.n, self.kernels)
 
     def run(self, x):
         x = x.contiguous()

@@ -109,6 +109,8 @@ def fill_args(a: L.ConvArgs, desc, x, w, scale, shift, alpha, residual, y):
     a.alpha = alpha.data_ptr() if alpha is not None else None
     a.residual = residual.data_ptr() if residual is not None else None
     a.y = y.data_ptr()
+    a.flags = 0
+    a.reserved = 0
     return a
 
 

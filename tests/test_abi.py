@@ -21,7 +21,7 @@ def _header_symbols():
 def test_header_symbols_all_exported():
     lib = L.load()
     syms = _header_symbols()
-    assert len(syms) >= 8
+    assert len(syms) >= 10
     assert sorted(L.SYMBOLS) == syms, "ctypes table and header disagree"
     for s in syms:
         assert hasattr(lib, s), s
@@ -31,7 +31,8 @@ def test_version_and_struct_layout():
     lib = L.load()
     assert lib.srmi_version() == 100
     assert C.sizeof(L.ConvDesc) == 23 * 4
-    assert C.sizeof(L.ConvArgs) == 96 + 7 * 8
+    assert C.sizeof(L.ConvArgs) == 96 + 7 * 8 + 8
+    assert L.ConvArgs.flags.offset == 152
     assert L.ConvArgs.x.offset == 96
 
 

@@ -69,8 +69,11 @@ def test_generator_bf16_psnr(golden_dir, name):
     gen = _make_gen(g, "bf16")
     with torch.no_grad():
         sr, feat = gen(torch.from_numpy(g["x"]).to(DEV))
-    kern = gen._plans.get(gen, g["x"].shape[0], g["x"].shape[2], g["x"].shape[3], 1).kernels
-    assert kern.count("c64_bf16") == 2 * int(g["num_block"]) + 3          # body + conv02 + 2 upsamplers
+    plan = gen._plans.get(gen, g["x"].shape[0], g["x"].shape[2], g["x"].shape[3], 1)
+    assert plan.kernels.count("c64_bf16") == 2 * int(g["num_block"]) + 3          # body + conv02 + 2 upsamplers
+    labels = [l for l, _, _ in plan.launches]
+    assert labels.count("resblock_bf16") == int(g["num_block"])                  # every ResBlock is ONE launch
+    assert labels[0] == "k9c3_bf16" and labels[-1] == "c64_thin_bf16"
     sr = sr.cpu().numpy()
     # synthetic ground truth at the reference's logged operating point (26.48 dB)
     rng = np.random.Generator(np.random.PCG64(99))

@@ -116,6 +116,13 @@ def test_layout_convert_exact():
     assert torch.equal(back, x)
     b = Fn.layout_convert(x, 2, 5, 7, 9, L.NCHW, L.NHWC, torch.bfloat16)
     assert torch.equal(b, x.permute(0, 2, 3, 1).contiguous().bfloat16())     # RNE cast matches torch's
+    # LDS-transposed NHWC -> NCHW path (C >= 8), ragged in pixels and channels
+    for (n, c, h, w) in [(2, 64, 7, 9), (1, 72, 5, 13), (3, 8, 1, 1)]:
+        t = torch.from_numpy(g.uniform(-1, 1, (n, h, w, c)).astype(np.float32)).to(DEV)
+        assert torch.equal(Fn.layout_convert(t, n, c, h, w, L.NHWC, L.NCHW, torch.float32), t.permute(0, 3, 1, 2).contiguous())
+        tb = t.bfloat16()
+        assert torch.equal(Fn.layout_convert(tb, n, c, h, w, L.NHWC, L.NCHW, torch.float32),
+                           tb.float().permute(0, 3, 1, 2).contiguous())
 
 
 @pytest.mark.parametrize("case", [
@@ -225,3 +232,58 @@ def test_k9c3_kernel(case):
     got = y.float().cpu().permute(0, 3, 1, 2)
     err = (got.double() - ref).abs()
     assert torch.all(err <= 2.0 ** -8 * (ref.abs() + 1.0)), err.max().item()
+
+
+@pytest.mark.parametrize("case", [
+    dict(N=2, H=11, W=13),             # small tile config, ragged
+    dict(N=1, H=4, W=32),              # exactly one small tile
+    dict(N=1, H=13, W=100),            # big 6x96 tiles, ragged both ways
+    dict(N=2, H=6, W=96),              # exactly one big tile per image
+    dict(N=1, H=24, W=192),
+])
+def test_fused_resblock_kernel(case):
+    """ResBlock in one launch == conv-affine-PReLU -> (bf16 T) -> conv-affine -> +x, the intermediate rounded to
+    bf16 exactly like the two-launch path; compared with the CPU restatement AND bit-for-bit with the unfused
+    kernels (same MFMA order per output element)."""
+    import ctypes as C
+    g = _rng(6)
+    N, H, W = case["N"], case["H"], case["W"]
+    x = torch.from_numpy(g.uniform(-1, 1, (N, 64, H, W)).astype(np.float32)).bfloat16().float()
+    ws, scs, shs = [], [], []
+    for _ in range(2):
+        ws.append(torch.from_numpy((g.standard_normal((64, 64, 3, 3)) / 24.0).astype(np.float32)).bfloat16().float())
+        scs.append(torch.from_numpy(g.uniform(0.5, 1.5, 64).astype(np.float32)))
+        shs.append(torch.from_numpy(g.uniform(-0.3, 0.3, 64).astype(np.float32)))
+    alpha = torch.tensor([0.25])
+    t_ref = _ref_fused(x, ws[0], scs[0], shs[0], L.ACT_PRELU, 0.0, alpha, None, 1, 1, 1, False).float().bfloat16().float()
+    ref = _ref_fused(t_ref, ws[1], scs[1], shs[1], L.ACT_NONE, 0.0, None, x, 1, 1, 1, False)
+
+    def desc(act):
+        return Fn.make_desc(N, H, W, 64, 64, 3, in_dtype=L.BF16, out_dtype=L.BF16, res_dtype=L.BF16,
+                            compute=L.COMPUTE_BF16, act=act)
+    d1, d2 = desc(L.ACT_PRELU), desc(L.ACT_NONE)
+    xd = x.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
+    wp = [Fn.pack_weights(d1, ws[0].to(DEV)), Fn.pack_weights(d2, ws[1].to(DEV))]
+    scd, shd, ad = [t.to(DEV) for t in scs], [t.to(DEV) for t in shs], alpha.to(DEV)
+    tmp = torch.full((N, H, W, 64), 3.0, dtype=torch.bfloat16, device=DEV)
+    y = torch.full((N, H, W, 64), -5.0, dtype=torch.bfloat16, device=DEV)
+    a1, a2 = L.ConvArgs(), L.ConvArgs()
+    Fn.fill_args(a1, d1, xd, wp[0], scd[0], shd[0], ad, None, tmp)
+    Fn.fill_args(a2, d2, tmp, wp[1], scd[1], shd[1], None, xd, y)
+    a1.flags = L.CONV_FUSE_NEXT
+    assert L.load().srmi_conv2d_can_fuse(C.byref(a1), C.byref(a2)) == 1
+    L.check(L.load().srmi_resblock_fwd(C.byref(a1), C.byref(a2), Fn.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.all(tmp == 3.0)                      # the intermediate is never materialised
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    err = (got.double() - ref).abs()
+    assert torch.all(err <= 2.0 ** -7 * (ref.abs() + 1.0)), err.max().item()
+    # unfused pair through the same ABI
+    y2 = torch.empty_like(y)
+    Fn.conv2d_fused(d1, xd, wp[0], scd[0], shd[0], ad, None, out=tmp)
+    Fn.conv2d_fused(d2, tmp, wp[1], scd[1], shd[1], None, xd, out=y2)
+    torch.cuda.synchronize()
+    assert torch.equal(y, y2)
+    # aliasing the input is refused before any launch
+    Fn.fill_args(a2, d2, tmp, wp[1], scd[1], shd[1], None, xd, xd)
+    assert L.load().srmi_resblock_fwd(C.byref(a1), C.byref(a2), Fn.stream_ptr()) == -2
