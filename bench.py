@@ -166,10 +166,8 @@ def main():
             sr, feat = gen(x)
         barrier()
         elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    from srmi.tiling import max_over_ranks
+    elapsed = max_over_ranks(elapsed, dist, dev)      # slowest rank
 
     out_mp_per_step = world * BATCH * (4 * LR_H) * (4 * LR_W) / 1e6
     value = out_mp_per_step * args.steps / elapsed
