@@ -37,20 +37,40 @@ constexpr int C64_PAR_BYTES = C64_MAX_CHUNKS * 3 * 64 * 4;  // per chunk: scale[
 
 // Every activation these kernels serve is  v >= 0 ? v : v * slope  (none: 1, ReLU: 0, LeakyReLU: param,
 // PReLU: alpha): branch-free, which keeps the unrolled epilogue small (instruction cache).
-// Stage scale / shift / slope of all chunks into LDS in kernel channel order, once per workgroup.
-__device__ __forceinline__ void c64_stage_params(float* par, const C64Epi& e, int nchunk, int tid, int nthreads) {
+// scale / shift / slope of all chunks are staged into LDS in kernel channel order, once per workgroup,
+// in two halves so that the global loads are IN FLIGHT TOGETHER with the input-tile loads (one memory
+// round trip in the kernel prologue, not two): c64_params_load before the tile loads, c64_params_store after.
+struct C64ParRegs { float sc[C64_MAX_CHUNKS / 4], sh[C64_MAX_CHUNKS / 4], sl[C64_MAX_CHUNKS / 4]; };
+
+__device__ __forceinline__ void c64_params_load(C64ParRegs& r, const C64Epi& e, int nchunk, int tid) {
     float slope0 = 1.f;
     if (e.act == SRMI_ACT_RELU) slope0 = 0.f;
     else if (e.act == SRMI_ACT_LRELU) slope0 = e.act_param;
     else if (e.act == SRMI_ACT_PRELU && !e.alpha_pc) slope0 = e.alpha[0];
     const bool pc = e.act == SRMI_ACT_PRELU && e.alpha_pc;
-    for (int i = tid; i < nchunk * 64; i += nthreads) {
-        const int s = i >> 6, cl = i & 63;
-        const int co = c64_conv_channel(e.mode, s, cl);
-        float* ps = par + s * 192;
-        ps[cl] = e.scale[co];
-        ps[64 + cl] = e.shift[co];
-        ps[128 + cl] = pc ? e.alpha[co] : slope0;
+#pragma unroll
+    for (int k = 0; k < C64_MAX_CHUNKS / 4; ++k) {
+        const int i = tid + 256 * k;
+        r.sc[k] = 0.f; r.sh[k] = 0.f; r.sl[k] = slope0;
+        if (i < nchunk * 64) {
+            const int co = c64_conv_channel(e.mode, i >> 6, i & 63);
+            r.sc[k] = e.scale[co];
+            r.sh[k] = e.shift[co];
+            if (pc) r.sl[k] = e.alpha[co];
+        }
+    }
+}
+
+__device__ __forceinline__ void c64_params_store(float* par, const C64ParRegs& r, int nchunk, int tid) {
+#pragma unroll
+    for (int k = 0; k < C64_MAX_CHUNKS / 4; ++k) {
+        const int i = tid + 256 * k;
+        if (i < nchunk * 64) {
+            float* ps = par + (i >> 6) * 192;
+            ps[i & 63] = r.sc[k];
+            ps[64 + (i & 63)] = r.sh[k];
+            ps[128 + (i & 63)] = r.sl[k];
+        }
     }
 }
 

@@ -96,6 +96,8 @@ __global__ __launch_bounds__(256, 1) void conv_c64_kernel(C64Params p) {
     if (ntap > 1) issue_tap(1);
     if (ntap > 2) issue_tap(2);
 
+    C64ParRegs pregs;
+    c64_params_load(pregs, p.epi, p.nchunk, tid);
     if (!(p.dbg & 1))
     // ---- stage the input halo tile: global (NHWC bf16) -> registers -> swizzled LDS ----------
     // All loads are issued before the first is consumed (clamped address + select, no branches):
@@ -136,8 +138,7 @@ __global__ __launch_bounds__(256, 1) void conv_c64_kernel(C64Params p) {
         pcol[k] = (t - prow[k] * TWT) * 16;
     }
 
-    c64_stage_params(par, p.epi, p.nchunk, tid, 256);
-
+    c64_params_store(par, pregs, p.nchunk, tid);
     // input tile written (own ds_writes: lgkmcnt; the staging loads' vmcnt(0) also retired taps 0..2)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();

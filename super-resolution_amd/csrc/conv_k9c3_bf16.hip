@@ -72,6 +72,8 @@ __global__ __launch_bounds__(256, 1) void conv_k9c3_kernel(K9Params p) {
         }
     }
 
+    C64ParRegs pregs;
+    c64_params_load(pregs, p.epi, 1, tid);
     // ---- input tile: (TH+8) x (TW+16) pixels -> [row][col][4] bf16, zero outside the image ---------
     {
         constexpr int NPIX = ROWS * ROWP;
@@ -103,8 +105,8 @@ __global__ __launch_bounds__(256, 1) void conv_k9c3_kernel(K9Params p) {
             if (idx < NPIX) *(u32x2*)(tile + idx * 8) = o;
         }
     }
-    c64_stage_params(par, p.epi, 1, tid, 256);
 
+    c64_params_store(par, pregs, 1, tid);
     int prow[PT], pcol[PT];
 #pragma unroll
     for (int k = 0; k < PT; ++k) {

@@ -85,6 +85,9 @@ __global__ __launch_bounds__(256, 1) void resblock_c64_kernel(ResBlockParams p) 
     issue_step(1);
     issue_step(2);
 
+    C64ParRegs pregs1, pregs2;
+    c64_params_load(pregs1, p.epi1, 1, tid);
+    c64_params_load(pregs2, p.epi2, 1, tid);
     // ---- stage the x halo tile (2-pixel ring) ----------------------------------------------------
     if (!(p.dbg & 1)) {
         constexpr int NCH = XR * XC * 8;
@@ -111,8 +114,8 @@ __global__ __launch_bounds__(256, 1) void resblock_c64_kernel(ResBlockParams p) 
             if (idx < NCH) *(u32x4*)(lds + P * 128 + ((ch ^ ((P >> 1) & 7)) << 4)) = z;
         }
     }
-    c64_stage_params(par, p.epi1, 1, tid, 256);
-    c64_stage_params(par + 192, p.epi2, 1, tid, 256);
+    c64_params_store(par, pregs1, 1, tid);
+    c64_params_store(par + 192, pregs2, 1, tid);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // also retires weight steps 0..2
     __builtin_amdgcn_s_barrier();
 
