@@ -8,13 +8,13 @@ PixelShuffle) forward, batch 16x3x96x96 LR, random init", the configuration nort
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = one `Generator.forward(lr) -> (sr, feat)` through the drop-in module surface (NCHW f32 in
-HBM -> NCHW f32 out), i.e. 37 fused conv launches + 1 re-layout of `feat`.  Inference shards by batch
+HBM -> NCHW f32 out), i.e. 37 convs in 21 launches (ResBlocks fused) + 1 re-layout of `feat`.  Inference shards by batch
 item with no collective: every rank runs the same per-GPU batch (weak scaling), the
 timed region is bracketed by barrier + synchronize, the slowest rank's time is used, and `value` is
 the whole-job aggregate.
 
 Extra objects on the JSON line:
-  roofline     - the dominant kernel (conv_c64_kernel, all 35 launches per step) against the dense
+  roofline     - the dominant kernel (resblock_c64_kernel: two fused 64->64 convs, 16 launches per step) against the dense
                  bf16 MFMA peak; its time is measured with HIP events on the launch stream.
   cpu_baseline - the oracle (plain torch.nn.functional restatement, pinned to the reference) timed on
                  this box's host cores, rank 0, N=1 only.
@@ -178,33 +178,44 @@ def main():
         # ---- roofline of the dominant kernel (HIP events, same process, same data) -------------
         with torch.no_grad():
             plan, units, kms = per_kernel_times(gen, x, reps=max(5, min(20, args.steps)))
-        # dominant kernel family = the 64-channel bf16 MFMA implicit-GEMM kernels (conv_c64_kernel and its
-        # two-conv fusion resblock_c64_kernel): 98 % of the network's FLOPs
-        dom = ("c64_bf16", "resblock_bf16") if args.compute == "bf16" else ("generic_f32",)
+        # dominant kernel = resblock_c64_kernel (two fused 64->64 convs; 16 launches = 59 % of the step's FLOPs and
+        # ~60 % of its time); the whole 64-channel MFMA family (resblock + conv_c64) is reported beside it.
+        dom = "resblock_bf16" if args.compute == "bf16" else "generic_f32"
+        fam = ("c64_bf16", "resblock_bf16") if args.compute == "bf16" else ("generic_f32",)
         peak = PEAK_BF16_TFLOPS if args.compute == "bf16" else PEAK_F32_MFMA_TFLOPS
-        per_layer, flops, t_dom, n_dom = {}, 0.0, 0.0, 0
+        per_layer, flops, t_dom, n_dom, f_fam, t_fam = {}, 0.0, 0.0, 0, 0.0, 0.0
         for u, (label, i, cnt) in enumerate(units):
             d = plan.args[i].d
             fl = sum(conv_flops(plan.args[i + c].d) for c in range(cnt))
             key = f"{label}:{d.Cin}->{plan.args[i + cnt - 1].d.Cout}@{d.H}x{d.W}k{d.kh}"
             e = per_layer.setdefault(key, [0, 0.0, 0.0])
             e[0] += 1; e[1] += kms[u]; e[2] += fl
-            if label in dom:
+            if label == dom:
                 flops += fl; t_dom += kms[u] * 1e-3; n_dom += 1
+            if label in fam:
+                f_fam += fl; t_fam += kms[u] * 1e-3
         achieved = flops / t_dom / 1e12
         layers = {k: {"launches": v[0], "ms": round(v[1], 4), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
                   for k, v in per_layer.items()}
-        idx = list(range(n_dom))
-        roofline = {"bound": "mfma", "kernel": "conv_c64_kernel + resblock_c64_kernel" if args.compute == "bf16" else "conv_generic_kernel",
-                    "launches_per_step": len(idx), "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": None,
-                    "avg_launch_us": round(t_dom / len(idx) * 1e6, 2),
-                    "flops_per_launch_avg": flops / len(idx),
+        traffic = None       # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_summary.py)
+        try:
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["kernels"]
+            traffic = next(v["hbm_bytes"] for k, v in pm.items() if "resblock_c64_kernel" in k) if args.compute == "bf16" else None
+        except Exception:
+            traffic = None
+        roofline = {"bound": "mfma", "kernel": "resblock_c64_kernel" if args.compute == "bf16" else "conv_generic_kernel",
+                    "launches_per_step": n_dom, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "avg_launch_us": round(t_dom / n_dom * 1e6, 2),
+                    "flops_per_launch": flops / n_dom,
+                    "algorithmic_bytes_per_launch": 2 * BATCH * LR_H * LR_W * 64 * 2,
+                    "mfma_family_tflops": round(f_fam / t_fam / 1e12, 2),
                     "whole_step_frac": round(value / world * 1e6 * FLOP_PER_OUT_PIXEL / 1e12 / peak, 4),
                     "sum_kernel_ms": round(float(kms.sum()), 4), "layers": layers,
-                    "method": "HIP events around every launch of instrumented forwards run right after the "
-                              "timed region (same process, stream, data); achieved = sum of algorithmic conv "
-                              "FLOPs of this kernel's launches / sum of their event times"}
+                    "method": "HIP events (torch's current stream = the launch stream) around every launch of "
+                              "instrumented forwards run right after the timed region, same process/data; achieved = "
+                              "algorithmic conv FLOPs of the kernel's launches / their event time; traffic = FETCH_SIZE x2 "
+                              "+ WRITE_SIZE per launch from separate rocprofv3 --pmc passes (profiles/r1_pmc_traffic.json)"}
         result = {
             "metric": "x4 SR output megapixels/sec (whole node)", "value": round(value, 2), "unit": "MP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
