@@ -86,6 +86,8 @@ typedef struct srmi_conv_desc {
                                first channel read, so a channel slice of a wider buffer can be consumed */
     int32_t out_cstride;    /* NHWC only: channels per pixel of the y buffer (0 = Cout / r^2) */
     int32_t out_coffset;    /* NHWC only: first channel written (concat-by-slice) */
+    int32_t res_cstride;    /* NHWC only: channels per pixel of the residual buffer (0 = dense = Cout / r^2): lets the
+                               residual be a channel slice of a concat buffer (RRDB `x + 0.2*y`, ESRGAN/untitled0.py:31-35) */
 } srmi_conv_desc;
 
 typedef struct srmi_conv_args {

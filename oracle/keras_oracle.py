@@ -1,0 +1,61 @@
+"""CPU restatement of the reference's two Keras generators (TEST INFRASTRUCTURE - see oracle/__init__.py).
+
+PARITY UNPINNED: TensorFlow/Keras, h5py and cv2 are absent from the container, the scripts train at import
+time and read Windows paths, and no outputs of these models are stored in the reference.
+The functions below restate the published Keras semantics at the reference's call sites; they are checked
+only structurally (parameter counts, shapes) and serve as the oracle of record for the HIP path.
+
+Keras semantics used: Conv2D(padding='same', stride 1) = symmetric k//2 zero padding for odd k, bias on;
+PReLU(shared_axes=[1,2]) = one alpha per channel; LeakyReLU(alpha=0.2); Concatenate() appends on the channel
+axis; tf.nn.depth_to_space(x, 2) is DCR: out[b, 2h+i, 2w+j, c] = in[b, h, w, (2i+j)*C + c].
+Tensors here are NCHW (torch); weights are OIHW (Keras stores HWIO: see srmi.keras_models.from_keras_hwio).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+
+def _conv(sd, name, x):
+    w = sd[name + ".weight"]
+    return F.conv2d(x, w, sd[name + ".bias"], padding=w.shape[-1] // 2)
+
+
+def srcnn_forward(sd, x):
+    """`model()`: conv9x9(1->128)+ReLU, conv3x3(128->64)+ReLU, conv5x5(64->1) linear  (SRCNN/srcnn.py:202-210)."""
+    x = F.relu(_conv(sd, "conv1", x))
+    x = F.relu(_conv(sd, "conv2", x))
+    return _conv(sd, "conv3", x)
+
+
+def depth_to_space_dcr(x, r):
+    n, c, h, w = x.shape
+    cf = c // (r * r)
+    return x.view(n, r, r, cf, h, w).permute(0, 3, 4, 1, 5, 2).reshape(n, cf, h * r, w * r)
+
+
+def _prelu_c(x, alpha):
+    return torch.where(x >= 0, x, x * alpha.view(1, -1, 1, 1))
+
+
+def rrdb_block(sd, prefix, x, num_dense_layers=3):
+    """`rrdb_block`: dense block (conv3x3 -> growth, LeakyReLU 0.2, concat) x L, conv3x3 -> filters, x0.2, + x
+    (ESRGAN/untitled0.py:18-35)."""
+    cat = x
+    for i in range(num_dense_layers):
+        d = F.leaky_relu(_conv(sd, f"{prefix}.dense.{i}", cat), 0.2)
+        cat = torch.cat([cat, d], dim=1)
+    return x + 0.2 * _conv(sd, f"{prefix}.compress", cat)
+
+
+def rrdbnet_forward(sd, x, num_blocks=16, num_dense_layers=3):
+    """`build_generator_esrgan` (ESRGAN/untitled0.py:37-67)."""
+    x = _prelu_c(_conv(sd, "head", x), sd["head_act.weight"])
+    first = x
+    for b in range(num_blocks):
+        x = rrdb_block(sd, f"blocks.{b}", x, num_dense_layers)
+    x = _conv(sd, "trunk", x) + first
+    for j in range(2):
+        x = depth_to_space_dcr(_conv(sd, f"up.{j}", x), 2)
+        x = _prelu_c(x, sd[f"up_act.{j}.weight"])
+    return torch.tanh(_conv(sd, "tail", x))

@@ -62,13 +62,15 @@ int conv_geom(const srmi_conv_desc& d, ConvGeom* g) {
     g->Wf = g->Wo * d.shuffle;
     g->in_cs = d.in_cstride ? d.in_cstride : d.Cin;
     g->out_cs = d.out_cstride ? d.out_cstride : g->Cf;
-    if (g->in_cs < d.Cin || d.out_coffset < 0 || g->out_cs < g->Cf + d.out_coffset) {
+    g->res_cs = d.res_cstride ? d.res_cstride : g->Cf;
+    if (g->in_cs < d.Cin || d.out_coffset < 0 || g->out_cs < g->Cf + d.out_coffset || g->res_cs < g->Cf) {
         set_error("conv desc: channel slice out of range (in_cs=%d Cin=%d out_cs=%d Cf=%d off=%d)", g->in_cs, d.Cin,
                   g->out_cs, g->Cf, d.out_coffset);
         return SRMI_EINVAL;
     }
     if ((d.in_layout == SRMI_NCHW && d.in_cstride && d.in_cstride != d.Cin) ||
-        (d.out_layout == SRMI_NCHW && (d.out_coffset || (d.out_cstride && d.out_cstride != g->Cf)))) {
+        (d.out_layout == SRMI_NCHW && (d.out_coffset || (d.out_cstride && d.out_cstride != g->Cf) ||
+                                       (d.res_cstride && d.res_cstride != g->Cf)))) {
         set_error("conv desc: channel slices need NHWC");
         return SRMI_EINVAL;
     }

@@ -49,6 +49,7 @@ struct ConvGeom {
     int Cf;            // final channels = Cout / r^2
     int Hf, Wf;        // final spatial size = Ho*r, Wo*r
     int in_cs, out_cs; // effective channel strides
+    int res_cs;        // residual channels per pixel
 };
 int conv_geom(const srmi_conv_desc& d, ConvGeom* g);  // validates, fills g
 

@@ -240,6 +240,7 @@ __global__ void c64_pack_kernel(const float* __restrict__ w, bf16_t* __restrict_
 
 bool c64_supported(const srmi_conv_desc& d) {
     if (d.compute != SRMI_COMPUTE_BF16) return false;
+    if (d.res_cstride && d.res_cstride != d.Cout / (d.shuffle * d.shuffle)) return false;   // dense residual only
     if (d.kh != 3 || d.kw != 3 || d.stride != 1 || d.pad != 1 || d.Cin != 64) return false;
     if (d.Cout % 64 != 0 || d.Cout <= 0 || d.Cout > 64 * C64_MAX_CHUNKS) return false;
     if (d.in_dtype != SRMI_BF16 || d.out_dtype != SRMI_BF16) return false;

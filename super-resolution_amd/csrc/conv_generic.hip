@@ -20,7 +20,7 @@ struct GenericParams {
     const void* x; const float* w; const float* scale; const float* shift; const float* alpha;
     const void* res; void* y;
     int N, H, W, Cin, Cout, kh, kw, stride, pad;
-    int Ho, Wo, Cf, Hf, Wf, in_cs, out_cs, out_co;
+    int Ho, Wo, Cf, Hf, Wf, in_cs, out_cs, out_co, res_cs;
     int in_bf16, out_bf16, res_bf16, in_nchw, out_nchw, vec_ok;
     int act; float act_param; int alpha_pc; int r; int dcr;
     int Cin_pad, Cout_pad, M;
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(GenericParams p) {
             } else {
                 const size_t px = ((size_t)n_r * p.Hf + Y) * p.Wf + X;
                 oidx = px * p.out_cs + p.out_co + c;
-                ridx = px * p.Cf + c;
+                ridx = px * p.res_cs + c;
             }
             if (p.res) val += p.res_bf16 ? bf2f(((const bf16_t*)p.res)[ridx]) : ((const float*)p.res)[ridx];
             if (p.out_bf16) ((bf16_t*)p.y)[oidx] = f2bf(val);
@@ -174,7 +174,7 @@ int generic_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     p.N = d.N; p.H = d.H; p.W = d.W; p.Cin = d.Cin; p.Cout = d.Cout; p.kh = d.kh; p.kw = d.kw;
     p.stride = d.stride; p.pad = d.pad;
     p.Ho = g.Ho; p.Wo = g.Wo; p.Cf = g.Cf; p.Hf = g.Hf; p.Wf = g.Wf;
-    p.in_cs = g.in_cs; p.out_cs = g.out_cs; p.out_co = d.out_coffset;
+    p.in_cs = g.in_cs; p.out_cs = g.out_cs; p.out_co = d.out_coffset; p.res_cs = g.res_cs;
     p.in_bf16 = d.in_dtype == SRMI_BF16; p.out_bf16 = d.out_dtype == SRMI_BF16;
     p.res_bf16 = d.res_dtype == SRMI_BF16;
     p.in_nchw = d.in_layout == SRMI_NCHW; p.out_nchw = d.out_layout == SRMI_NCHW;

@@ -179,6 +179,7 @@ __global__ void k9c3_pack_kernel(const float* __restrict__ w, bf16_t* __restrict
 
 bool k9c3_supported(const srmi_conv_desc& d) {
     if (d.compute != SRMI_COMPUTE_BF16) return false;
+    if (d.res_cstride && d.res_cstride != d.Cout / (d.shuffle * d.shuffle)) return false;   // dense residual only
     if (d.kh != 9 || d.kw != 9 || d.stride != 1 || d.pad != 4) return false;
     if (d.Cin < 1 || d.Cin > 3 || d.Cout != 64 || d.shuffle != 1) return false;
     if (d.out_dtype != SRMI_BF16 || d.out_layout != SRMI_NHWC) return false;

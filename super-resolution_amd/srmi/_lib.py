@@ -42,6 +42,7 @@ class ConvDesc(C.Structure):
         ("alpha_per_channel", C.c_int32),
         ("shuffle", C.c_int32), ("shuffle_order", C.c_int32),
         ("in_cstride", C.c_int32), ("out_cstride", C.c_int32), ("out_coffset", C.c_int32),
+        ("res_cstride", C.c_int32),
     ]
 
 

@@ -58,7 +58,8 @@ class _Seq:
         return t
 
     def add(self, block_or_parts, x, y, N, H, W, *, residual=None, shuffle=1, in_layout=L.NHWC, out_layout=L.NHWC,
-            in_dtype=None, out_dtype=None, weight=None, k=None, stride=None, cin=None, cout=None, fuse_next=False):
+            in_dtype=None, out_dtype=None, weight=None, k=None, stride=None, cin=None, cout=None, fuse_next=False,
+            shuffle_order=L.SHUFFLE_CRD, in_cstride=0, out_cstride=0, out_coffset=0, res_cstride=0, out_scale=None):
         c2d, bn, act = block_or_parts if isinstance(block_or_parts, tuple) else conv_parts(block_or_parts)
         if bn is not None and bn.training:
             raise NotImplementedError("srmi: train-mode BatchNorm is not part of the inference plan")
@@ -74,13 +75,24 @@ class _Seq:
                             out_dtype=self.adt if out_dtype is None else out_dtype,
                             res_dtype=self.adt, in_layout=in_layout, out_layout=out_layout,
                             compute=self.compute, act=code, act_param=param, alpha_per_channel=apc,
-                            shuffle=shuffle)
+                            shuffle=shuffle, shuffle_order=shuffle_order, in_cstride=in_cstride,
+                            out_cstride=out_cstride, out_coffset=out_coffset, res_cstride=res_cstride)
         wp = Fn.pack_weights(desc, w.reshape(cout_, cin_, k_, k_))
         scale, shift = Fn.fold_bn(c2d.bias, bn, cout_, self.device)
+        if out_scale is not None:          # e.g. RRDB's `x * 0.2` (ESRGAN/untitled0.py:32): folded, not a pass
+            scale, shift = scale * out_scale, shift * out_scale
         if alpha is not None:
             alpha = alpha.detach()
             if alpha.dtype != torch.float32:
                 raise TypeError("PReLU weight must be float32")
+            if apc and alpha.numel() != cout_:
+                # per-channel PReLU applied AFTER a sub-pixel shuffle: expand to the conv's channel order
+                rr = shuffle * shuffle
+                if alpha.numel() * rr != cout_:
+                    raise ValueError("per-channel PReLU size does not match the conv")
+                alpha = alpha.repeat(rr) if shuffle_order == L.SHUFFLE_DCR else alpha.repeat_interleave(rr)
+                alpha = alpha.contiguous()
+                self.keep.append(alpha)
         self.keep += [wp, scale, shift]
         self.layers.append((desc, x, wp, scale, shift, alpha, residual, y, fuse_next))
         self.kernels.append(L.kernel_name(desc))

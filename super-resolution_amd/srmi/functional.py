@@ -58,7 +58,7 @@ def act_of(module):
 def make_desc(N, H, W, Cin, Cout, k, stride=1, pad=None, in_dtype=L.F32, out_dtype=L.F32, res_dtype=L.F32,
               in_layout=L.NHWC, out_layout=L.NHWC, compute=L.COMPUTE_F32, act=L.ACT_NONE, act_param=0.0,
               alpha_per_channel=0, shuffle=1, shuffle_order=L.SHUFFLE_CRD, in_cstride=0, out_cstride=0,
-              out_coffset=0) -> L.ConvDesc:
+              out_coffset=0, res_cstride=0) -> L.ConvDesc:
     kh, kw = (k, k) if isinstance(k, int) else k
     d = L.ConvDesc()
     d.N, d.H, d.W, d.Cin, d.Cout = N, H, W, Cin, Cout
@@ -69,6 +69,7 @@ def make_desc(N, H, W, Cin, Cout, k, stride=1, pad=None, in_dtype=L.F32, out_dty
     d.act, d.act_param, d.alpha_per_channel = act, act_param, alpha_per_channel
     d.shuffle, d.shuffle_order = shuffle, shuffle_order
     d.in_cstride, d.out_cstride, d.out_coffset = in_cstride, out_cstride, out_coffset
+    d.res_cstride = res_cstride
     return d
 
 

@@ -1,0 +1,157 @@
+"""The reference's two Keras generators as torch modules on libsrmi's kernels:
+
+  * `SRCNN`   - SRCNN/srcnn.py:199-210: conv9x9(1->128)+ReLU, conv3x3(128->64)+ReLU, conv5x5(64->1); BASELINE config 2
+                ("9-1-5, 64/32") is `SRCNN(k=(9, 1, 5), ch=(64, 32))`.
+  * `RRDBNet` - ESRGAN/untitled0.py:18-67 (same in "25-ESRGAN lpips/esrgan.py:34-85"): conv3x3+PReLU(per channel) ·
+                N x [3 x (conv3x3 -> 32, LeakyReLU 0.2, concat) -> conv3x3(160 -> 64) x 0.2 + x] · conv3x3 + first ·
+                2 x [conv3x3(64 -> 256), depth_to_space(2), PReLU(per channel)] · conv3x3(64 -> 3) tanh.
+                The reference builds 16 blocks; BASELINE config 4 asks 23: `RRDBNet(num_blocks=23)`.
+
+The Keras scripts are not importable (no TensorFlow here) and build their graph inline, so there is no module API
+to mirror; parameters are ordinary `nn.Conv2d` (OIHW) so torch tooling works, and `from_keras_hwio` converts a Keras
+kernel.  Tensors are NCHW like the rest of this package (Keras is NHWC).  The channel concat of the dense block is
+never materialised as a copy: every dense conv writes its 32 channels into a slice of one 160-channel NHWC buffer
+(`out_cstride/out_coffset`) and reads the leading channels of the same buffer (`in_cstride`).
+Parity: unpinned (see oracle/keras_oracle.py); tests compare with that restatement.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import functional as Fn
+from .engine import PlanCache, _Seq
+from .ops import _guard
+from .srgan_model import _COMPUTE, _ComputeMixin
+
+
+def from_keras_hwio(w):
+    """Keras Conv2D kernel (kh, kw, in, out) -> torch OIHW."""
+    return torch.as_tensor(w).permute(3, 2, 0, 1).contiguous()
+
+
+def _c(cin, cout, k):
+    return nn.Conv2d(cin, cout, k, padding=k // 2, bias=True)
+
+
+class _Plan:
+    def run(self, x):
+        x = x.contiguous().float()
+        self._x = x
+        y = torch.empty(self.out_shape, dtype=torch.float32, device=self.dev)
+        self.args[0].x = x.data_ptr()
+        self.args[self.n - 1].y = y.data_ptr()
+        L.check(L.load().srmi_conv2d_fwd_seq(self.args, self.n, Fn.stream_ptr()))
+        return y
+
+
+class SRCNNPlan(_Plan):
+    def __init__(self, m, N, H, W, compute):
+        dev = next(m.parameters()).device
+        s = _Seq(dev, compute)
+        relu = nn.ReLU()
+        b1 = s.buf(N, H, W, m.conv1.out_channels)
+        s.add((m.conv1, None, relu), None, b1, N, H, W, in_layout=L.NCHW, in_dtype=L.F32)
+        b2 = s.buf(N, H, W, m.conv2.out_channels)
+        s.add((m.conv2, None, relu), b1, b2, N, H, W)
+        self.out_shape = (N, m.conv3.out_channels, H, W)
+        y0 = torch.empty(self.out_shape, dtype=torch.float32, device=dev)
+        s.add((m.conv3, None, None), b2, y0, N, H, W, out_layout=L.NCHW, out_dtype=L.F32)
+        self.dev = dev
+        self.args, self.n = s.finish()
+        self.kernels, self._seq = s.kernels, s
+
+
+class SRCNN(nn.Module, _ComputeMixin):
+    def __init__(self, k=(9, 3, 5), ch=(128, 64), in_ch=1):
+        super().__init__()
+        self.conv1 = _c(in_ch, ch[0], k[0])
+        self.conv2 = _c(ch[0], ch[1], k[1])
+        self.conv3 = _c(ch[1], in_ch, k[2])
+        for c in (self.conv1, self.conv2, self.conv3):     # Keras: glorot_uniform kernel, zero bias
+            nn.init.xavier_uniform_(c.weight)
+            nn.init.zeros_(c.bias)
+        self._plans = PlanCache(SRCNNPlan)
+
+    def forward(self, x):
+        _guard(x, self)
+        N, _, H, W = x.shape
+        return self._plans.get(self, N, H, W, _COMPUTE[self.compute]).run(x)
+
+
+class RRDBPlan(_Plan):
+    def __init__(self, m, N, H, W, compute):
+        dev = next(m.parameters()).device
+        s = _Seq(dev, compute)
+        nf, g, nd = m.n_feats, m.growth, m.num_dense_layers
+        ctot = nf + nd * g
+        lrelu = nn.LeakyReLU(0.2)
+        # block b works in cat[b & 1]: x in channels [0, nf), dense outputs appended behind it
+        cat = [s.buf(N, H, W, ctot), s.buf(N, H, W, ctot)]
+        first = s.buf(N, H, W, nf)
+        s.add((m.head, None, m.head_act), None, first, N, H, W, in_layout=L.NCHW, in_dtype=L.F32)
+        nb = len(m.blocks)
+        # the head output is needed twice (long skip, and x of block 0 inside the concat buffer)
+        for b, blk in enumerate(m.blocks):
+            buf = cat[b & 1]
+            if b == 0:
+                # x of block 0 = head output: produce it straight into the slice as well (same conv, second store)
+                s.add((m.head, None, m.head_act), None, buf, N, H, W, in_layout=L.NCHW, in_dtype=L.F32,
+                      out_cstride=ctot, out_coffset=0)
+                self._second_head = len(s.layers) - 1
+            for i, dc in enumerate(blk.dense):
+                s.add((dc, None, lrelu), buf, buf, N, H, W, in_cstride=ctot, out_cstride=ctot, out_coffset=nf + i * g)
+            # compress: (conv + b) * 0.2 + x ; x = buf[..., :nf] (a channel slice -> res_cstride)
+            last = b == nb - 1
+            dst = s.buf(N, H, W, nf) if last else cat[(b + 1) & 1]
+            s.add((blk.compress, None, None), buf, dst, N, H, W, in_cstride=ctot, residual=buf, res_cstride=ctot,
+                  out_cstride=nf if last else ctot, out_coffset=0, out_scale=0.2)
+            trunk_in = dst
+        if not nb:
+            trunk_in = first
+        t = s.buf(N, H, W, nf)
+        s.add((m.trunk, None, None), trunk_in, t, N, H, W, residual=first)
+        x, h, w = t, H, W
+        for j in range(2):
+            y = s.buf(N, 2 * h, 2 * w, nf)
+            s.add((m.up[j], None, m.up_act[j]), x, y, N, h, w, shuffle=2, shuffle_order=L.SHUFFLE_DCR)
+            x, h, w = y, 2 * h, 2 * w
+        self.out_shape = (N, m.tail.out_channels, h, w)
+        y0 = torch.empty(self.out_shape, dtype=torch.float32, device=dev)
+        s.add((m.tail, None, nn.Tanh()), x, y0, N, h, w, out_layout=L.NCHW, out_dtype=L.F32)
+        self.dev = dev
+        self.args, self.n = s.finish()
+        self.kernels, self._seq = s.kernels, s
+
+    def run(self, x):
+        x = x.contiguous().float()
+        if hasattr(self, "_second_head"):
+            self.args[self._second_head].x = x.data_ptr()
+        return super().run(x)
+
+
+class _RRDB(nn.Module):
+    def __init__(self, nf, growth, nd):
+        super().__init__()
+        self.dense = nn.ModuleList([_c(nf + i * growth, growth, 3) for i in range(nd)])
+        self.compress = _c(nf + nd * growth, nf, 3)
+
+
+class RRDBNet(nn.Module, _ComputeMixin):
+    def __init__(self, num_blocks=16, n_feats=64, growth=32, num_dense_layers=3, img_ch=3):
+        super().__init__()
+        self.n_feats, self.growth, self.num_dense_layers = n_feats, growth, num_dense_layers
+        self.head = _c(img_ch, n_feats, 3)
+        self.head_act = nn.PReLU(n_feats, init=0.0)            # Keras PReLU: alpha per channel, initialised to 0
+        self.blocks = nn.ModuleList([_RRDB(n_feats, growth, num_dense_layers) for _ in range(num_blocks)])
+        self.trunk = _c(n_feats, n_feats, 3)
+        self.up = nn.ModuleList([_c(n_feats, 4 * n_feats, 3) for _ in range(2)])
+        self.up_act = nn.ModuleList([nn.PReLU(n_feats, init=0.0) for _ in range(2)])
+        self.tail = _c(n_feats, img_ch, 3)
+        self._plans = PlanCache(RRDBPlan)
+
+    def forward(self, x):
+        _guard(x, self)
+        N, _, H, W = x.shape
+        return self._plans.get(self, N, H, W, _COMPUTE[self.compute]).run(x)

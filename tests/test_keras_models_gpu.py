@@ -1,0 +1,81 @@
+"""GPU: the Keras-derived generators (SRCNN, ESRGAN-style RRDB) against oracle/keras_oracle.py.
+PARITY UNPINNED w.r.t. the reference (TensorFlow absent, no stored outputs - SURVEY 8c c5): the oracle is a
+restatement of the Keras call sites; these tests pin the HIP path to it."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import keras_oracle as K
+from srmi.keras_models import SRCNN, RRDBNet, from_keras_hwio
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _randomise(m, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() == 4:
+                p.copy_(torch.randn(p.shape, generator=g) * (0.8 / (p.shape[1] * p.shape[2] * p.shape[3]) ** 0.5))
+            elif n.endswith("bias"):
+                p.copy_(torch.empty(p.shape).uniform_(-0.1, 0.1, generator=g))
+            else:                                   # per-channel PReLU slopes
+                p.copy_(torch.empty(p.shape).uniform_(0.05, 0.4, generator=g))
+
+
+def _psnr01(a, b):
+    return 10 * np.log10(1.0 / (float(((a.double() - b.double()) ** 2).mean()) / 4.0))
+
+
+def test_param_counts_match_reference_summary():
+    assert sum(p.numel() for p in SRCNN().parameters()) == 10_496 + 73_792 + 1_601
+    m = RRDBNet(num_blocks=16)
+    per_block = (64 * 32 + 96 * 32 + 128 * 32) * 9 + 3 * 32 + 160 * 64 * 9 + 64
+    assert sum(p.numel() for p in m.blocks[0].parameters()) == per_block
+    assert from_keras_hwio(torch.zeros(3, 3, 64, 32)).shape == (32, 64, 3, 3)
+
+
+@pytest.mark.parametrize("kw,shape", [(dict(), (2, 1, 20, 28)), (dict(k=(9, 1, 5), ch=(64, 32)), (1, 1, 33, 17))])
+def test_srcnn_fp32_and_bf16(kw, shape):
+    m = SRCNN(**kw)
+    _randomise(m, 1)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.rand(shape, generator=torch.Generator().manual_seed(2))
+    with torch.no_grad():
+        ref = K.srcnn_forward(sd, x)
+        m = m.to(DEV).eval()
+        y = m(x.to(DEV)).cpu()
+        assert y.shape == ref.shape
+        assert (y - ref).abs().max().item() <= 1e-4
+        yb = m.set_compute("bf16")(x.to(DEV)).cpu()
+    assert (yb - ref).abs().max().item() <= 3e-2
+
+
+@pytest.mark.parametrize("nb,shape", [(2, (1, 3, 12, 16)), (3, (2, 3, 9, 7)), (0, (1, 3, 8, 8))])
+def test_rrdbnet_fp32(nb, shape):
+    m = RRDBNet(num_blocks=nb)
+    _randomise(m, 3)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.rand(shape, generator=torch.Generator().manual_seed(4)) * 2 - 1
+    with torch.no_grad():
+        ref = K.rrdbnet_forward(sd, x, num_blocks=nb)
+        y = m.to(DEV).eval()(x.to(DEV)).cpu()
+    assert y.shape == ref.shape == (shape[0], 3, 4 * shape[2], 4 * shape[3])
+    assert (y - ref).abs().max().item() / 2.0 <= 1e-4            # [0,1] pixel scale
+
+
+def test_rrdbnet_bf16_psnr():
+    m = RRDBNet(num_blocks=4)
+    _randomise(m, 5)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.rand((2, 3, 24, 40), generator=torch.Generator().manual_seed(6)) * 2 - 1
+    with torch.no_grad():
+        ref = K.rrdbnet_forward(sd, x, num_blocks=4)
+        m = m.to(DEV).eval().set_compute("bf16")
+        y = m(x.to(DEV)).cpu()
+        plan = m._plans.get(m, 2, 24, 40, 1)
+    assert plan.kernels.count("c64_bf16") == 3 and plan.kernels[-1] == "c64_thin_bf16"
+    p = _psnr01(y, ref)
+    print("RRDB bf16 PSNR vs fp32 oracle: %.1f dB" % p)
+    assert p >= 40.0
