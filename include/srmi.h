@@ -149,6 +149,36 @@ int srmi_layout_convert(const void* src, void* dst, int32_t N, int32_t C, int32_
                         int32_t src_layout, int32_t src_dtype, int32_t dst_layout, int32_t dst_dtype,
                         void* stream);
 
+/* ---- losses and metrics (HBM-bound reductions) ------------------------------------------------
+ * All results are written to DEVICE memory (no host synchronisation).  `ws` is a caller-owned device
+ * workspace of at least SRMI_REDUCE_WS_BYTES bytes, 8-byte aligned; it holds the per-workgroup f64
+ * partials of the deterministic two-stage reduction (no atomics: same input => same bits). */
+#define SRMI_REDUCE_WS_BYTES 16384
+
+/* out[0] = mean((a-b)^2) over n f32 elements.  Replaces nn.MSELoss (P/mode.py:89, :169; P/losses.py:30). */
+int srmi_mse_loss(const float* a, const float* b, size_t n, float* out, void* ws, void* stream);
+
+/* out[0] = mean(-(t*log(p) + (1-t)*log(1-p))), logs clamped at -100.  Replaces nn.BCELoss on the
+ * discriminator probabilities (P/mode.py:136, :153-154, :171). */
+int srmi_bce_loss(const float* p, const float* t, size_t n, float* out, void* ws, void* stream);
+
+/* out[0] = weight * 2 * (sum(dh^2)/count_h + sum(dw^2)/count_w) / N on an NCHW f32 tensor.
+ * Replaces TVLoss.forward (P/losses.py:46-55). */
+int srmi_tv_loss(const float* x, int32_t N, int32_t C, int32_t H, int32_t W, float weight, float* out, void* ws,
+                 void* stream);
+
+/* Y-channel PSNR and SSIM of one image pair, both 3xHxW planar f32 in [-1,1] (the generator's range):
+ *   ((v+1)/2) -> rgb2ycbcr luma (BT.601, 16..235) -> crop `border` pixels on every side ->
+ *   out[0] = mse(Y/255), out[1] = PSNR in dB (data_range 1), out[2] = mean SSIM with a win x win uniform
+ *   window, sample covariance, data_range 1.0 on the UNSCALED luma exactly as the reference calls it.
+ * `sr` is dense 3xHxW; `gt` is the top-left HxW corner of a dense 3 x gt_H x gt_W tensor (P/mode.py:353).
+ * clip != 0 clamps sr to [-1,1] first (P/mode.py:360 does, P/mode.py:24-45 does not).  win = 0 skips SSIM
+ * (out[2] = NaN); otherwise win is odd, 3 <= win <= 7 and <= the cropped side (P/mode.py:40-43).
+ * out is 3 f64 in device memory.  Replaces calculate_metrics' PSNR/SSIM (P/mode.py:24-45) and
+ * test()'s PSNR (P/mode.py:369-373). */
+int srmi_y_psnr_ssim(const float* sr, const float* gt, int32_t H, int32_t W, int32_t gt_H, int32_t gt_W,
+                     int32_t border, int32_t clip, int32_t win, double* out, void* ws, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

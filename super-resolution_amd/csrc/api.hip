@@ -23,6 +23,11 @@ int hip_check(hipError_t e, const char* what) {
 int layout_convert(const void* src, void* dst, int N, int C, int H, int W, int sl, int sd, int dl, int dd,
                    hipStream_t s);
 
+int pair_loss(int op, const float* a, const float* b, size_t n, float* out, void* ws, hipStream_t s);
+int tv_loss(const float* x, int N, int C, int H, int W, float weight, float* out, void* ws, hipStream_t s);
+int y_metrics(const float* sr, const float* gt, int H, int W, int gt_H, int gt_W, int border, int clip, int win,
+              double* out, void* ws, hipStream_t s);
+
 static bool is_dtype(int v) { return v == SRMI_F32 || v == SRMI_BF16; }
 static bool is_layout(int v) { return v == SRMI_NHWC || v == SRMI_NCHW; }
 
@@ -219,6 +224,49 @@ int srmi_layout_convert(const void* src, void* dst, int32_t N, int32_t C, int32_
     if ((size_t)N * C * H * W == 0) return SRMI_OK;
     if (!src || !dst) { set_error("layout_convert: NULL buffer"); return SRMI_EINVAL; }
     return layout_convert(src, dst, N, C, H, W, src_layout, src_dtype, dst_layout, dst_dtype, (hipStream_t)stream);
+}
+
+static int check_reduce(const char* what, const void* a, const void* b, const void* out, const void* ws) {
+    if (!a || !b || !out || !ws) { set_error("%s: NULL argument", what); return SRMI_EINVAL; }
+    if ((uintptr_t)ws % 8) { set_error("%s: workspace must be 8-byte aligned", what); return SRMI_EINVAL; }
+    return SRMI_OK;
+}
+
+int srmi_mse_loss(const float* a, const float* b, size_t n, float* out, void* ws, void* stream) {
+    int rc = check_reduce("mse_loss", a, b, out, ws);
+    if (rc) return rc;
+    return pair_loss(0, a, b, n, out, ws, (hipStream_t)stream);  // n == 0: 0/0 = NaN, as torch
+}
+
+int srmi_bce_loss(const float* p, const float* t, size_t n, float* out, void* ws, void* stream) {
+    int rc = check_reduce("bce_loss", p, t, out, ws);
+    if (rc) return rc;
+    return pair_loss(1, p, t, n, out, ws, (hipStream_t)stream);
+}
+
+int srmi_tv_loss(const float* x, int32_t N, int32_t C, int32_t H, int32_t W, float weight, float* out, void* ws,
+                 void* stream) {
+    int rc = check_reduce("tv_loss", x, x, out, ws);
+    if (rc) return rc;
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) { set_error("tv_loss: bad dims %dx%dx%dx%d", N, C, H, W); return SRMI_EINVAL; }
+    return tv_loss(x, N, C, H, W, weight, out, ws, (hipStream_t)stream);
+}
+
+int srmi_y_psnr_ssim(const float* sr, const float* gt, int32_t H, int32_t W, int32_t gt_H, int32_t gt_W,
+                     int32_t border, int32_t clip, int32_t win, double* out, void* ws, void* stream) {
+    int rc = check_reduce("y_psnr_ssim", sr, gt, out, ws);
+    if (rc) return rc;
+    if ((uintptr_t)out % 8) { set_error("y_psnr_ssim: out must be 8-byte aligned"); return SRMI_EINVAL; }
+    if (H <= 0 || W <= 0 || gt_H < H || gt_W < W || border < 0 || H - 2 * border <= 0 || W - 2 * border <= 0) {
+        set_error("y_psnr_ssim: bad geometry H=%d W=%d gt=%dx%d border=%d", H, W, gt_H, gt_W, border);
+        return SRMI_EINVAL;
+    }
+    const int side = (H < W ? H : W) - 2 * border;
+    if (win != 0 && (win < 3 || win > 7 || win % 2 == 0 || win > side)) {
+        set_error("y_psnr_ssim: window %d must be odd, 3..7 and <= the cropped side %d", win, side);
+        return SRMI_EINVAL;
+    }
+    return y_metrics(sr, gt, H, W, gt_H, gt_W, border, clip, win, out, ws, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -1,0 +1,83 @@
+"""Loss reductions of the SRGAN step on the HIP kernels (csrc/metrics.hip).
+
+Mirrors the reference's call sites: ``nn.MSELoss`` (P/mode.py:89, :169), ``nn.BCELoss``
+(P/mode.py:136), ``TVLoss`` (P/losses.py:41-59).  Forward values only (inference / logging); results
+stay on the device as 0-d float32 tensors, no host synchronisation.  No CPU fallback.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .functional import require_cuda, stream_ptr
+
+_WS = {}
+
+
+def _workspace(device):
+    ws = _WS.get(device)
+    if ws is None:
+        ws = _WS[device] = torch.empty(L.REDUCE_WS_BYTES // 8, dtype=torch.float64, device=device)
+    return ws
+
+
+def _f32c(t, what):
+    require_cuda(t, what)
+    if t.dtype != torch.float32:
+        raise TypeError(f"srmi: {what} must be float32, got {t.dtype}")
+    return t.contiguous()
+
+
+def mse_loss(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """``nn.MSELoss()(a, b)`` (mean reduction)."""
+    if a.shape != b.shape:
+        raise ValueError(f"srmi.mse_loss: shapes differ {tuple(a.shape)} vs {tuple(b.shape)}")
+    a, b = _f32c(a, "input"), _f32c(b, "target")
+    out = torch.empty((), dtype=torch.float32, device=a.device)
+    L.check(L.load().srmi_mse_loss(a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(),
+                                   _workspace(a.device).data_ptr(), stream_ptr()))
+    return out
+
+
+def bce_loss(p: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+    """``nn.BCELoss()(p, t)`` (mean reduction, logs clamped at -100 like torch)."""
+    if p.shape != t.shape:
+        raise ValueError(f"srmi.bce_loss: shapes differ {tuple(p.shape)} vs {tuple(t.shape)}")
+    p, t = _f32c(p, "input"), _f32c(t, "target")
+    out = torch.empty((), dtype=torch.float32, device=p.device)
+    L.check(L.load().srmi_bce_loss(p.data_ptr(), t.data_ptr(), p.numel(), out.data_ptr(),
+                                   _workspace(p.device).data_ptr(), stream_ptr()))
+    return out
+
+
+class MSELoss(nn.Module):
+    def forward(self, a, b):
+        return mse_loss(a, b)
+
+
+class BCELoss(nn.Module):
+    def forward(self, p, t):
+        return bce_loss(p, t)
+
+
+class TVLoss(nn.Module):
+    """Same constructor and call as the reference's ``TVLoss`` (P/losses.py:41-59)."""
+
+    def __init__(self, tv_loss_weight=1):
+        super().__init__()
+        self.tv_loss_weight = tv_loss_weight
+
+    def forward(self, x):
+        if x.dim() != 4:
+            raise ValueError("TVLoss expects an NCHW tensor")
+        x = _f32c(x, "input")
+        N, C_, H, W = x.shape
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        L.check(L.load().srmi_tv_loss(x.data_ptr(), N, C_, H, W, float(self.tv_loss_weight), out.data_ptr(),
+                                      _workspace(x.device).data_ptr(), stream_ptr()))
+        return out
+
+    @staticmethod
+    def tensor_size(t):
+        return t.size()[1] * t.size()[2] * t.size()[3]

@@ -1,0 +1,57 @@
+"""Y-channel PSNR / SSIM on the device (csrc/metrics.hip), mirroring ``calculate_metrics``
+(P/mode.py:24-45) and the PSNR of ``test`` (P/mode.py:353-373).
+
+The reference moves each image to the host and calls skimage; here the colour conversion, border
+crop and reductions are one pass of HIP kernels over the tensors where they already live.  The LPIPS
+and DISTS scores of ``calculate_metrics`` need third-party pretrained networks and are out of scope.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib as L
+from .functional import require_cuda, stream_ptr
+from .losses import _workspace
+
+
+def ssim_window(h, w, scale):
+    """win_size rule of P/mode.py:40-43 on the cropped luma plane."""
+    win = min(7, min(h - 2 * scale, w - 2 * scale))
+    if win % 2 == 0:
+        win -= 1
+    return win
+
+
+def y_psnr_ssim(gt: torch.Tensor, output: torch.Tensor, scale: int = 1, clip: bool = False, ssim: bool = True):
+    """(psnr, ssim) of image 0 of the batch as a 3-element float64 DEVICE tensor [mse, psnr, ssim].
+
+    gt may be larger than output; its top-left corner is used (P/mode.py:353)."""
+    require_cuda(gt, "gt")
+    require_cuda(output, "output")
+    if output.dim() != 4 or gt.dim() != 4 or output.shape[1] != 3 or gt.shape[1] != 3:
+        raise ValueError("y_psnr_ssim expects Nx3xHxW tensors")
+    o = output[0].float().contiguous()
+    g = gt[0].float().contiguous()
+    H, W = o.shape[1:]
+    gH, gW = g.shape[1:]
+    if scale < 1:
+        raise ValueError("scale must be >= 1 (the reference slices [scale:-scale])")
+    win = ssim_window(H, W, scale) if ssim else 0
+    if ssim and win < 3:
+        raise ValueError(f"image {H}x{W} too small for SSIM after cropping {scale} px")
+    res = torch.empty(3, dtype=torch.float64, device=o.device)
+    L.check(L.load().srmi_y_psnr_ssim(o.data_ptr(), g.data_ptr(), H, W, gH, gW, scale, int(clip), win,
+                                      res.data_ptr(), _workspace(o.device).data_ptr(), stream_ptr()))
+    return res
+
+
+def calculate_metrics(gt, output, device=None, scale=1):
+    """Drop-in for the PSNR/SSIM half of ``calculate_metrics`` (P/mode.py:24-45): returns
+    ``(psnr, ssim)`` as Python floats (one device->host copy of 24 bytes)."""
+    r = y_psnr_ssim(gt, output, scale=scale, clip=False, ssim=True).cpu()
+    return float(r[1]), float(r[2])
+
+
+def test_psnr(gt, output, scale):
+    """PSNR of ``test`` (P/mode.py:353-373): output clipped to [-1,1], gt cropped to output's size."""
+    return float(y_psnr_ssim(gt, output, scale=scale, clip=True, ssim=False)[1])
