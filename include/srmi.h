@@ -179,6 +179,72 @@ int srmi_tv_loss(const float* x, int32_t N, int32_t C, int32_t H, int32_t W, flo
 int srmi_y_psnr_ssim(const float* sr, const float* gt, int32_t H, int32_t W, int32_t gt_H, int32_t gt_W,
                      int32_t border, int32_t clip, int32_t win, double* out, void* ws, void* stream);
 
+/* ---- training step (fp32): train-mode BatchNorm, epilogue fwd/bwd, dgrad, wgrad, pool, loss grads, Adam ----
+ * The training path keeps the conv and its epilogue as separate launches because train-mode BatchNorm needs
+ * the batch statistics of the whole conv output before it can normalise (P/ops.py:24-26 with the module in
+ * .train(), P/mode.py:101, :149, :164):   z = conv(x) + bias  (srmi_conv2d_fwd, act NONE)  ->  batch stats  ->
+ * y = store(act(bn(z))) + residual.  All tensors dense NHWC f32.  `ws` must hold srmi_train_workspace_bytes(C)
+ * bytes (f64 per-channel accumulators), 8-byte aligned. */
+typedef struct srmi_epi_desc {
+    int32_t N, H, W, C;        /* geometry of z, the conv output BEFORE any sub-pixel shuffle */
+    int32_t act;               /* SRMI_ACT_* */
+    float act_param;           /* LeakyReLU slope */
+    int32_t alpha_per_channel; /* PReLU: alpha[C / r^2] instead of a scalar */
+    int32_t shuffle;           /* sub-pixel factor of the store (y is [N, H*r, W*r, C/r^2]); 1 = none */
+    int32_t shuffle_order;     /* SRMI_SHUFFLE_* */
+    int32_t bn;                /* 1: y = act((z - mean) * rstd * gamma + beta) */
+} srmi_epi_desc;
+
+int srmi_train_workspace_bytes(int32_t C, size_t* bytes);
+
+/* Batch statistics of z [M pixels, C channels]: mean[c], rstd[c] = 1/sqrt(biased_var + eps); when
+ * running_mean / running_var are non-NULL they are updated in place as nn.BatchNorm2d does
+ * (r = (1-momentum) r + momentum * stat, unbiased variance).  P/ops.py:24-26. */
+int srmi_bn_train_stats(const float* z, int64_t M, int32_t C, float eps, float momentum, float* mean, float* rstd,
+                        float* running_mean, float* running_var, void* ws, void* stream);
+
+/* y = store(act(bn(z))) + residual.  mean/rstd/gamma/beta are read only when d->bn; residual (shaped like y)
+ * may be NULL.  Replaces BatchNorm2d + activation + PixelShuffle + `res += x` (P/ops.py:24-29, :47, :75-83). */
+int srmi_epilogue_fwd(const srmi_epi_desc* d, const float* z, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, const float* alpha, const float* residual, float* y,
+                      void* stream);
+
+/* Backward of srmi_epilogue_fwd w.r.t. z and the parameters, given dy (shaped like y):
+ *   dz      gradient w.r.t. the conv output (same shape as z);
+ *   dsum1   [C]: d beta when d->bn, else the conv bias gradient (sum of dz over pixels);
+ *   dsum2   [C]: d gamma (d->bn only; may be NULL otherwise);
+ *   dalpha  [1] or [C/r^2]: PReLU slope gradient (may be NULL when act != PRELU).
+ * The residual's gradient is dy itself.  autograd of the same modules in the reference (P/mode.py:105, :160, :178). */
+int srmi_epilogue_bwd(const srmi_epi_desc* d, const float* z, const float* dy, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, const float* alpha, float* dz, float* dsum1,
+                      float* dsum2, float* dalpha, void* ws, void* stream);
+
+/* Input gradient of the conv described by `d` (geometry fields only; NHWC f32): dx[N,H,W,Cin] from
+ * dz[N,Ho,Wo,Cout].  The weights are packed once per step by srmi_conv2d_dgrad_pack_weights. */
+int srmi_conv2d_dgrad_packed_weight_bytes(const srmi_conv_desc* d, size_t* bytes);
+int srmi_conv2d_dgrad_pack_weights(const srmi_conv_desc* d, const float* w_oihw, void* w_packed, void* stream);
+int srmi_conv2d_dgrad(const srmi_conv_desc* d, const float* dz, const void* w_packed, float* dx, void* stream);
+
+/* Weight gradient: dw (OIHW f32, the nn.Conv2d.weight.grad layout) = sum over pixels of dz (x) x; dw is
+ * overwritten.  x is NHWC f32 with d->in_cstride channels per pixel (0 = Cin). */
+int srmi_conv2d_wgrad(const srmi_conv_desc* d, const float* x, const float* dz, float* dw, void* stream);
+
+/* 2x2 stride-2 max pool, NHWC f32 (VGG19 features, P/vgg19.py:13-17); H, W are the INPUT size. */
+int srmi_maxpool2x2_fwd(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+int srmi_maxpool2x2_bwd(const float* x, const float* dy, float* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                        void* stream);
+
+/* Gradients of srmi_mse_loss / srmi_bce_loss; gout is the upstream scalar gradient in device memory.
+ * da or db may be NULL. */
+int srmi_mse_loss_bwd(const float* a, const float* b, const float* gout, size_t n, float* da, float* db,
+                      void* stream);
+int srmi_bce_loss_bwd(const float* p, const float* t, const float* gout, size_t n, float* dp, void* stream);
+
+/* One Adam update of a flat f32 parameter buffer (torch.optim.Adam defaults; P/mode.py:90, :138-139);
+ * `step` is the 1-based step count used for the bias corrections. */
+int srmi_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
+                   float beta1, float beta2, float eps, int32_t step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

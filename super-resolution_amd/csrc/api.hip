@@ -28,6 +28,26 @@ int tv_loss(const float* x, int N, int C, int H, int W, float weight, float* out
 int y_metrics(const float* sr, const float* gt, int H, int W, int gt_H, int gt_W, int border, int clip, int win,
               double* out, void* ws, hipStream_t s);
 
+int bn_train_stats(const float* z, long long M, int C, float eps, float momentum, float* mean, float* rstd,
+                   float* rmean, float* rvar, void* ws, hipStream_t s);
+int epilogue_fwd(const srmi_epi_desc& d, const float* z, const float* mean, const float* rstd, const float* gamma,
+                 const float* beta, const float* alpha, const float* residual, float* y, hipStream_t s);
+int epilogue_bwd(const srmi_epi_desc& d, const float* z, const float* dy, const float* mean, const float* rstd,
+                 const float* gamma, const float* beta, const float* alpha, float* dz, float* dsum1, float* dsum2,
+                 float* dalpha, void* ws, hipStream_t s);
+int maxpool_fwd(const float* x, float* y, int N, int H, int W, int C, hipStream_t s);
+int maxpool_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, hipStream_t s);
+int mse_bwd(const float* a, const float* b, const float* gout, size_t n, float* da, float* db, hipStream_t s);
+int bce_bwd(const float* p, const float* t, const float* gout, size_t n, float* dp, hipStream_t s);
+int adam_step(float* param, const float* grad, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+              float eps, int step, hipStream_t s);
+size_t generic_dgrad_packed_bytes(const srmi_conv_desc& d);
+int generic_dgrad_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s);
+int generic_dgrad_launch(const srmi_conv_desc& d, const ConvGeom& g, const float* dz, const float* w_dgrad, float* dx,
+                         hipStream_t s);
+int wgrad_launch(const srmi_conv_desc& d, const ConvGeom& g, const float* x, const float* dz, float* dw,
+                 hipStream_t s);
+
 static bool is_dtype(int v) { return v == SRMI_F32 || v == SRMI_BF16; }
 static bool is_layout(int v) { return v == SRMI_NHWC || v == SRMI_NCHW; }
 
@@ -267,6 +287,147 @@ int srmi_y_psnr_ssim(const float* sr, const float* gt, int32_t H, int32_t W, int
         return SRMI_EINVAL;
     }
     return y_metrics(sr, gt, H, W, gt_H, gt_W, border, clip, win, out, ws, (hipStream_t)stream);
+}
+
+static int epi_check(const char* what, const srmi_epi_desc* d) {
+    if (!d) { set_error("%s: NULL descriptor", what); return SRMI_EINVAL; }
+    if (d->N < 0 || d->H < 0 || d->W < 0 || d->C <= 0 || d->shuffle < 1 || d->C % (d->shuffle * d->shuffle) != 0 ||
+        d->act < SRMI_ACT_NONE || d->act > SRMI_ACT_SIGMOID ||
+        (d->shuffle_order != SRMI_SHUFFLE_CRD && d->shuffle_order != SRMI_SHUFFLE_DCR)) {
+        set_error("%s: bad descriptor N=%d H=%d W=%d C=%d r=%d act=%d", what, d->N, d->H, d->W, d->C, d->shuffle, d->act);
+        return SRMI_EINVAL;
+    }
+    return SRMI_OK;
+}
+
+int srmi_train_workspace_bytes(int32_t C, size_t* bytes) {
+    if (C <= 0 || !bytes) { set_error("train_workspace_bytes: bad arguments"); return SRMI_EINVAL; }
+    *bytes = (size_t)3 * C * sizeof(double);
+    return SRMI_OK;
+}
+
+int srmi_bn_train_stats(const float* z, int64_t M, int32_t C, float eps, float momentum, float* mean, float* rstd,
+                        float* running_mean, float* running_var, void* ws, void* stream) {
+    if (!z || !mean || !rstd || !ws || M <= 0 || C <= 0 || (uintptr_t)ws % 8) {
+        set_error("bn_train_stats: bad arguments (M=%lld C=%d)", (long long)M, C);
+        return SRMI_EINVAL;
+    }
+    return bn_train_stats(z, M, C, eps, momentum, mean, rstd, running_mean, running_var, ws, (hipStream_t)stream);
+}
+
+int srmi_epilogue_fwd(const srmi_epi_desc* d, const float* z, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, const float* alpha, const float* residual, float* y,
+                      void* stream) {
+    int rc = epi_check("epilogue_fwd", d);
+    if (rc) return rc;
+    if (!z || !y || (d->bn && (!mean || !rstd || !gamma || !beta)) || (d->act == SRMI_ACT_PRELU && !alpha)) {
+        set_error("epilogue_fwd: NULL argument");
+        return SRMI_EINVAL;
+    }
+    return epilogue_fwd(*d, z, mean, rstd, gamma, beta, alpha, residual, y, (hipStream_t)stream);
+}
+
+int srmi_epilogue_bwd(const srmi_epi_desc* d, const float* z, const float* dy, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, const float* alpha, float* dz, float* dsum1,
+                      float* dsum2, float* dalpha, void* ws, void* stream) {
+    int rc = epi_check("epilogue_bwd", d);
+    if (rc) return rc;
+    if (!z || !dy || !dz || !ws || (uintptr_t)ws % 8 || (d->bn && (!mean || !rstd || !gamma || !beta)) ||
+        (d->act == SRMI_ACT_PRELU && !alpha)) {
+        set_error("epilogue_bwd: NULL or misaligned argument");
+        return SRMI_EINVAL;
+    }
+    return epilogue_bwd(*d, z, dy, mean, rstd, gamma, beta, alpha, dz, dsum1, dsum2, dalpha, ws, (hipStream_t)stream);
+}
+
+static int grad_geom(const char* what, const srmi_conv_desc* d, ConvGeom* g) {
+    if (!d) { set_error("%s: NULL descriptor", what); return SRMI_EINVAL; }
+    int rc = conv_geom(*d, g);
+    if (rc) return rc;
+    if (d->in_layout != SRMI_NHWC || d->out_layout != SRMI_NHWC || d->in_dtype != SRMI_F32 || d->out_dtype != SRMI_F32 ||
+        d->shuffle != 1 || d->out_coffset != 0 || (d->out_cstride && d->out_cstride != d->Cout)) {
+        set_error("%s: gradients are NHWC f32, dense dz, no sub-pixel store (run the epilogue backward first)", what);
+        return SRMI_EUNSUPPORTED;
+    }
+    return SRMI_OK;
+}
+
+int srmi_conv2d_dgrad_packed_weight_bytes(const srmi_conv_desc* d, size_t* bytes) {
+    ConvGeom g;
+    int rc = grad_geom("dgrad_packed_weight_bytes", d, &g);
+    if (rc) return rc;
+    if (!bytes) { set_error("dgrad_packed_weight_bytes: NULL argument"); return SRMI_EINVAL; }
+    *bytes = generic_dgrad_packed_bytes(*d);
+    return SRMI_OK;
+}
+
+int srmi_conv2d_dgrad_pack_weights(const srmi_conv_desc* d, const float* w_oihw, void* w_packed, void* stream) {
+    ConvGeom g;
+    int rc = grad_geom("dgrad_pack_weights", d, &g);
+    if (rc) return rc;
+    if (!w_oihw || !w_packed) { set_error("dgrad_pack_weights: NULL argument"); return SRMI_EINVAL; }
+    return generic_dgrad_pack(*d, w_oihw, w_packed, (hipStream_t)stream);
+}
+
+int srmi_conv2d_dgrad(const srmi_conv_desc* d, const float* dz, const void* w_packed, float* dx, void* stream) {
+    ConvGeom g;
+    int rc = grad_geom("dgrad", d, &g);
+    if (rc) return rc;
+    if (d->in_cstride && d->in_cstride != d->Cin) { set_error("dgrad: dx must be dense"); return SRMI_EUNSUPPORTED; }
+    if ((long long)d->N * d->H * d->W == 0) return SRMI_OK;
+    if (!dz || !w_packed || !dx) { set_error("dgrad: NULL argument"); return SRMI_EINVAL; }
+    if ((long long)d->N * g.Ho * g.Wo == 0)
+        return hip_check(hipMemsetAsync(dx, 0, (size_t)d->N * d->H * d->W * d->Cin * sizeof(float), (hipStream_t)stream),
+                         "dgrad memset");
+    return generic_dgrad_launch(*d, g, dz, (const float*)w_packed, dx, (hipStream_t)stream);
+}
+
+int srmi_conv2d_wgrad(const srmi_conv_desc* d, const float* x, const float* dz, float* dw, void* stream) {
+    ConvGeom g;
+    int rc = grad_geom("wgrad", d, &g);
+    if (rc) return rc;
+    if (!dw) { set_error("wgrad: NULL dw"); return SRMI_EINVAL; }
+    rc = hip_check(hipMemsetAsync(dw, 0, (size_t)d->Cout * d->Cin * d->kh * d->kw * sizeof(float), (hipStream_t)stream),
+                   "wgrad memset");
+    if (rc) return rc;
+    if ((long long)d->N * g.Ho * g.Wo == 0) return SRMI_OK;
+    if (!x || !dz) { set_error("wgrad: NULL argument"); return SRMI_EINVAL; }
+    return wgrad_launch(*d, g, x, dz, dw, (hipStream_t)stream);
+}
+
+int srmi_maxpool2x2_fwd(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    if (N < 0 || H < 0 || W < 0 || C <= 0) { set_error("maxpool_fwd: bad dims"); return SRMI_EINVAL; }
+    if ((size_t)N * (H / 2) * (W / 2) == 0) return SRMI_OK;
+    if (!x || !y) { set_error("maxpool_fwd: NULL argument"); return SRMI_EINVAL; }
+    return maxpool_fwd(x, y, N, H, W, C, (hipStream_t)stream);
+}
+
+int srmi_maxpool2x2_bwd(const float* x, const float* dy, float* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                        void* stream) {
+    if (N < 0 || H < 0 || W < 0 || C <= 0) { set_error("maxpool_bwd: bad dims"); return SRMI_EINVAL; }
+    if ((size_t)N * H * W == 0) return SRMI_OK;
+    if (!x || !dx || (!dy && (H / 2) * (W / 2) > 0)) { set_error("maxpool_bwd: NULL argument"); return SRMI_EINVAL; }
+    return maxpool_bwd(x, dy, dx, N, H, W, C, (hipStream_t)stream);
+}
+
+int srmi_mse_loss_bwd(const float* a, const float* b, const float* gout, size_t n, float* da, float* db,
+                      void* stream) {
+    if (!a || !b || !gout || (!da && !db)) { set_error("mse_loss_bwd: NULL argument"); return SRMI_EINVAL; }
+    return mse_bwd(a, b, gout, n, da, db, (hipStream_t)stream);
+}
+
+int srmi_bce_loss_bwd(const float* p, const float* t, const float* gout, size_t n, float* dp, void* stream) {
+    if (!p || !t || !gout || !dp) { set_error("bce_loss_bwd: NULL argument"); return SRMI_EINVAL; }
+    return bce_bwd(p, t, gout, n, dp, (hipStream_t)stream);
+}
+
+int srmi_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
+                   float beta1, float beta2, float eps, int32_t step, void* stream) {
+    if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1) {
+        set_error("adam_step: NULL argument or step < 1");
+        return SRMI_EINVAL;
+    }
+    return adam_step(param, grad, exp_avg, exp_avg_sq, n, lr, beta1, beta2, eps, step, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -24,6 +24,8 @@ struct GenericParams {
     int in_bf16, out_bf16, res_bf16, in_nchw, out_nchw, vec_ok;
     int act; float act_param; int alpha_pc; int r; int dcr;
     int Cin_pad, Cout_pad, M;
+    hipStream_t stream;
+    int transposed;  // dgrad: gather dz at (o + pad - k) / stride where divisible
 };
 
 template <int NT>
@@ -53,10 +55,22 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(GenericParams p) {
     const size_t HW = (size_t)p.H * p.W;
 
     for (int ky = 0; ky < p.kh; ++ky) {
-        const int iy = oy * p.stride - p.pad + ky;
+        int iy = oy * p.stride - p.pad + ky;
+        bool vy = true;
+        if (p.transposed) {
+            const int ty = oy + p.pad - ky;
+            vy = ty >= 0 && ty % p.stride == 0;
+            iy = ty / p.stride;
+        }
         for (int kx = 0; kx < p.kw; ++kx) {
-            const int ix = ox * p.stride - p.pad + kx;
-            const bool v = mvalid && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+            int ix = ox * p.stride - p.pad + kx;
+            bool vx = true;
+            if (p.transposed) {
+                const int tx = ox + p.pad - kx;
+                vx = tx >= 0 && tx % p.stride == 0;
+                ix = tx / p.stride;
+            }
+            const bool v = mvalid && vy && vx && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
             const int tap = ky * p.kw + kx;
             const float* wt = p.w + (size_t)tap * p.Cin_pad * p.Cout_pad + co0 + i;
             const size_t pix = v ? (((size_t)n * p.H + iy) * p.W + ix) : 0;
@@ -103,7 +117,7 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(GenericParams p) {
         const int co = co0 + 32 * t + i;
         const bool cvalid = co < p.Cout;
         const int coc = cvalid ? co : 0;
-        const float sc = p.scale[coc], sh = p.shift[coc];
+        const float sc = p.scale ? p.scale[coc] : 1.f, sh = p.shift ? p.shift[coc] : 0.f;
         const float al = (p.act == SRMI_ACT_PRELU) ? p.alpha[p.alpha_pc ? coc : 0] : 0.f;
         int c = coc, si = 0, sj = 0;
         if (p.r > 1) {
@@ -151,6 +165,38 @@ __global__ void generic_pack_kernel(const float* __restrict__ w, float* __restri
     }
 }
 
+// dgrad operand: OIHW f32 -> [tap][Cout_pad8 (contracted)][Cin_pad32 (produced)] f32, same tap index as forward
+__global__ void generic_pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin, int Cout,
+                                          int kh, int kw, int K_pad, int N_pad, size_t total) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(idx % N_pad);
+        const size_t t1 = idx / N_pad;
+        const int co = (int)(t1 % K_pad);
+        const int tap = (int)(t1 / K_pad);
+        float v = 0.f;
+        if (co < Cout && ci < Cin) {
+            const int ky = tap / kw, kx = tap % kw;
+            v = w[(((size_t)co * Cin + ci) * kh + ky) * kw + kx];
+        }
+        out[idx] = v;
+    }
+}
+
+size_t generic_dgrad_packed_bytes(const srmi_conv_desc& d) {
+    return (size_t)d.kh * d.kw * round_up(d.Cout, 8) * round_up(d.Cin, 32) * sizeof(float);
+}
+
+int generic_dgrad_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s) {
+    const int K_pad = round_up(d.Cout, 8), N_pad = round_up(d.Cin, 32);
+    const size_t total = (size_t)d.kh * d.kw * K_pad * N_pad;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(generic_pack_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w_oihw, (float*)w_packed,
+                       d.Cin, d.Cout, d.kh, d.kw, K_pad, N_pad, total);
+    return hip_check(hipGetLastError(), "generic_pack_dgrad_kernel");
+}
+
 size_t generic_packed_bytes(const srmi_conv_desc& d) {
     return (size_t)d.kh * d.kw * round_up(d.Cin, 8) * round_up(d.Cout, 32) * sizeof(float);
 }
@@ -166,9 +212,12 @@ int generic_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, h
     return hip_check(hipGetLastError(), "generic_pack_kernel");
 }
 
+static int generic_run(const struct GenericParams& p);
+
 int generic_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     const srmi_conv_desc& d = a.d;
     GenericParams p;
+    p.stream = s;
     p.x = a.x; p.w = (const float*)a.w; p.scale = a.scale; p.shift = a.shift; p.alpha = a.alpha;
     p.res = a.residual; p.y = a.y;
     p.N = d.N; p.H = d.H; p.W = d.W; p.Cin = d.Cin; p.Cout = d.Cout; p.kh = d.kh; p.kw = d.kw;
@@ -186,16 +235,45 @@ int generic_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     const long long M = (long long)d.N * g.Ho * g.Wo;
     if (M > 0x7fffffffLL) { set_error("generic conv: N*Ho*Wo = %lld exceeds int32", M); return SRMI_EINVAL; }
     p.M = (int)M;
+    p.transposed = 0;
     if (p.M == 0) return SRMI_OK;
+    return generic_run(p);
+}
+
+static int generic_run(const GenericParams& p) {
+    hipStream_t s = p.stream;
     const unsigned gx = (unsigned)((p.M + 127) / 128);
-    if (d.Cout > 32) {
-        dim3 grid(gx, (unsigned)((d.Cout + 63) / 64));
+    if (p.Cout > 32) {
+        dim3 grid(gx, (unsigned)((p.Cout + 63) / 64));
         hipLaunchKernelGGL(conv_generic_kernel<2>, grid, dim3(256), 0, s, p);
     } else {
         dim3 grid(gx, 1);
         hipLaunchKernelGGL(conv_generic_kernel<1>, grid, dim3(256), 0, s, p);
     }
     return hip_check(hipGetLastError(), "conv_generic_kernel");
+}
+
+// dx[N,H,W,Cin] = conv_transpose(dz[N,Ho,Wo,Cout], w): the forward descriptor `d` describes the conv whose
+// input gradient is wanted; dz and dx are dense NHWC f32.
+int generic_dgrad_launch(const srmi_conv_desc& d, const ConvGeom& g, const float* dz, const float* w_dgrad, float* dx,
+                         hipStream_t s) {
+    GenericParams p;
+    memset(&p, 0, sizeof(p));
+    p.stream = s;
+    p.x = dz; p.w = w_dgrad; p.y = dx;
+    p.N = d.N; p.H = g.Ho; p.W = g.Wo; p.Cin = d.Cout; p.Cout = d.Cin; p.kh = d.kh; p.kw = d.kw;
+    p.stride = d.stride; p.pad = d.pad;
+    p.Ho = d.H; p.Wo = d.W; p.Cf = d.Cin; p.Hf = d.H; p.Wf = d.W;
+    p.in_cs = d.Cout; p.out_cs = d.Cin; p.out_co = 0; p.res_cs = d.Cin;
+    p.vec_ok = d.Cout % 8 == 0 && ((uintptr_t)dz % 16) == 0;
+    p.act = SRMI_ACT_NONE; p.r = 1;
+    p.Cin_pad = round_up(d.Cout, 8); p.Cout_pad = round_up(d.Cin, 32);
+    const long long M = (long long)d.N * d.H * d.W;
+    if (M > 0x7fffffffLL) { set_error("dgrad: N*H*W = %lld exceeds int32", M); return SRMI_EINVAL; }
+    p.M = (int)M;
+    p.transposed = 1;
+    if (p.M == 0) return SRMI_OK;
+    return generic_run(p);
 }
 
 }  // namespace srmi

@@ -1,0 +1,363 @@
+// Training-step pointwise / per-channel kernels (HBM-bound): train-mode BatchNorm statistics,
+// the conv epilogue (normalise -> activation -> sub-pixel store -> residual) forward and backward,
+// 2x2 max-pool forward/backward, MSE/BCE loss gradients and the Adam update.
+//
+// Tensors are dense NHWC f32.  Per-channel sums use lanes along the channel axis (coalesced rows),
+// four waves along pixels, an LDS tree across the waves and one f64 global atomic per channel and
+// workgroup; the f64 accumulators live in the caller's workspace.
+#include "common.h"
+
+namespace srmi {
+
+constexpr int CH_BLOCK = 256;
+
+struct EpiParams {
+    const float* z; const float* dy; const float* mean; const float* rstd; const float* gamma; const float* beta;
+    const float* alpha; const float* residual;
+    float* y; float* dz;
+    double* acc;  // [3][C] : S1, S2, dalpha (dalpha uses [Cf] or [1])
+    long long M;  // pixels N*H*W
+    int H, W, C, Cf, r, dcr, act, alpha_pc, bn;
+    float act_param;
+};
+
+// conv-order element (pixel m, channel c) -> (index into the final tensor, final channel)
+__device__ __forceinline__ size_t final_index(const EpiParams& p, long long m, int c, int* cf_out) {
+    if (p.r == 1) { *cf_out = c; return (size_t)m * p.C + c; }
+    const int rr = p.r * p.r;
+    int cf, sidx;
+    if (p.dcr) { cf = c % p.Cf; sidx = c / p.Cf; } else { cf = c / rr; sidx = c % rr; }
+    const int si = sidx / p.r, sj = sidx % p.r;
+    const int ox = (int)(m % p.W);
+    const long long t = m / p.W;
+    const int oy = (int)(t % p.H);
+    const long long n = t / p.H;
+    *cf_out = cf;
+    return (((size_t)n * p.H * p.r + (size_t)oy * p.r + si) * ((size_t)p.W * p.r) + (size_t)ox * p.r + sj) * p.Cf + cf;
+}
+
+__device__ __forceinline__ float slope_of(const EpiParams& p, int cf) {
+    if (p.act == SRMI_ACT_PRELU) return p.alpha[p.alpha_pc ? cf : 0];
+    if (p.act == SRMI_ACT_LRELU) return p.act_param;
+    return 0.f;  // ReLU
+}
+
+// ---- per-channel sum / sum of squares (BatchNorm batch statistics) --------------------------------
+__global__ __launch_bounds__(CH_BLOCK) void bn_stats_kernel(const float* __restrict__ z, long long M, int C,
+                                                            double* __restrict__ acc) {
+    __shared__ double l1[CH_BLOCK], l2[CH_BLOCK];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + tx;
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C)
+        for (long long m = (long long)blockIdx.x * 4 + ty; m < M; m += (long long)gridDim.x * 4) {
+            const double v = (double)z[(size_t)m * C + c];
+            s1 += v; s2 += v * v;
+        }
+    l1[threadIdx.x] = s1; l2[threadIdx.x] = s2;
+    __syncthreads();
+    if (ty == 0 && c < C) {
+        s1 = l1[tx] + l1[tx + 64] + l1[tx + 128] + l1[tx + 192];
+        s2 = l2[tx] + l2[tx + 64] + l2[tx + 128] + l2[tx + 192];
+        atomicAdd(acc + c, s1);
+        atomicAdd(acc + C + c, s2);
+    }
+}
+
+// mean, 1/sqrt(var+eps) and the running-statistics update of nn.BatchNorm2d (momentum, unbiased running var)
+__global__ void bn_finalize_kernel(const double* __restrict__ acc, long long M, int C, float eps, float momentum,
+                                   float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ rmean,
+                                   float* __restrict__ rvar) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mu = acc[c] / (double)M;
+    double var = acc[C + c] / (double)M - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[c] = (float)mu;
+    rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+    if (rmean) rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mu);
+    if (rvar) {
+        const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unbiased);
+    }
+}
+
+// ---- epilogue forward: y = store(act(bn(z))) + residual -------------------------------------------
+__global__ __launch_bounds__(CH_BLOCK) void epilogue_fwd_kernel(EpiParams p) {
+    const size_t total = (size_t)p.M * p.C;
+    for (size_t idx = (size_t)blockIdx.x * CH_BLOCK + threadIdx.x; idx < total; idx += (size_t)gridDim.x * CH_BLOCK) {
+        const int c = (int)(idx % p.C);
+        const long long m = (long long)(idx / p.C);
+        float v = p.z[idx];
+        if (p.bn) v = (v - p.mean[c]) * p.rstd[c] * p.gamma[c] + p.beta[c];
+        int cf;
+        const size_t o = final_index(p, m, c, &cf);
+        const float al = (p.act == SRMI_ACT_PRELU) ? p.alpha[p.alpha_pc ? cf : 0] : 0.f;
+        v = apply_act(v, p.act, p.act_param, al);
+        if (p.residual) v += p.residual[o];
+        p.y[o] = v;
+    }
+}
+
+// ---- epilogue backward, pass 1: g = dy * act'(u) -> dz, per-channel S1 = sum g, S2 = sum g*zhat, dalpha --
+__global__ __launch_bounds__(CH_BLOCK) void epilogue_bwd_kernel(EpiParams p) {
+    __shared__ double l1[CH_BLOCK], l2[CH_BLOCK], l3[CH_BLOCK];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int c = blockIdx.y * 64 + tx;
+    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int cf_thread = 0;
+    if (c < p.C) {
+        float mu = 0.f, rs = 1.f, ga = 1.f, be = 0.f;
+        if (p.bn) { mu = p.mean[c]; rs = p.rstd[c]; ga = p.gamma[c]; be = p.beta[c]; }
+        for (long long m = (long long)blockIdx.x * 4 + ty; m < p.M; m += (long long)gridDim.x * 4) {
+            const size_t idx = (size_t)m * p.C + c;
+            const float zh = (p.z[idx] - mu) * rs;        // = z when !bn
+            const float u = p.bn ? zh * ga + be : zh;
+            int cf;
+            const size_t o = final_index(p, m, c, &cf);
+            cf_thread = cf;
+            const float g0 = p.dy[o];
+            float g;
+            switch (p.act) {
+                case SRMI_ACT_PRELU: case SRMI_ACT_LRELU: case SRMI_ACT_RELU: {
+                    const float sl = slope_of(p, cf);
+                    g = u > 0.f ? g0 : g0 * sl;
+                    if (p.act == SRMI_ACT_PRELU && !(u > 0.f)) s3 += (double)g0 * (double)u;
+                    break;
+                }
+                case SRMI_ACT_TANH: { const float t = tanhf(u); g = g0 * (1.f - t * t); break; }
+                case SRMI_ACT_SIGMOID: { const float sg = 1.f / (1.f + expf(-u)); g = g0 * sg * (1.f - sg); break; }
+                default: g = g0;
+            }
+            p.dz[idx] = g;
+            s1 += (double)g;
+            s2 += (double)g * (double)zh;
+        }
+    }
+    l1[threadIdx.x] = s1; l2[threadIdx.x] = s2; l3[threadIdx.x] = s3;
+    __syncthreads();
+    if (ty == 0 && c < p.C) {
+        s1 = l1[tx] + l1[tx + 64] + l1[tx + 128] + l1[tx + 192];
+        s2 = l2[tx] + l2[tx + 64] + l2[tx + 128] + l2[tx + 192];
+        s3 = l3[tx] + l3[tx + 64] + l3[tx + 128] + l3[tx + 192];
+        atomicAdd(p.acc + c, s1);
+        if (p.bn) atomicAdd(p.acc + p.C + c, s2);
+        if (p.act == SRMI_ACT_PRELU) atomicAdd(p.acc + 2 * p.C + (p.alpha_pc ? cf_thread : 0), s3);
+    }
+}
+
+// pass 2 (BN only): dz = gamma * rstd * (g - S1/M - zhat * S2/M)
+__global__ __launch_bounds__(CH_BLOCK) void bn_bwd_apply_kernel(EpiParams p) {
+    const size_t total = (size_t)p.M * p.C;
+    const double invM = 1.0 / (double)p.M;
+    for (size_t idx = (size_t)blockIdx.x * CH_BLOCK + threadIdx.x; idx < total; idx += (size_t)gridDim.x * CH_BLOCK) {
+        const int c = (int)(idx % p.C);
+        const float rs = p.rstd[c];
+        const float zh = (p.z[idx] - p.mean[c]) * rs;
+        const float m1 = (float)(p.acc[c] * invM), m2 = (float)(p.acc[p.C + c] * invM);
+        p.dz[idx] = p.gamma[c] * rs * (p.dz[idx] - m1 - zh * m2);
+    }
+}
+
+// f64 accumulators -> f32 parameter gradients
+__global__ void epilogue_bwd_finalize_kernel(const double* __restrict__ acc, int C, int n_alpha, int bn,
+                                             float* __restrict__ dsum1, float* __restrict__ dsum2,
+                                             float* __restrict__ dalpha) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        if (dsum1) dsum1[c] = (float)acc[c];
+        if (bn && dsum2) dsum2[c] = (float)acc[C + c];
+    }
+    if (dalpha && c < n_alpha) dalpha[c] = (float)acc[2 * C + c];
+}
+
+// ---- 2x2 stride-2 max pool (VGG19, P/vgg19.py) NHWC f32 -------------------------------------------------
+__global__ __launch_bounds__(CH_BLOCK) void maxpool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                               int N, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)N * Ho * Wo * C;
+    for (size_t idx = (size_t)blockIdx.x * CH_BLOCK + threadIdx.x; idx < total; idx += (size_t)gridDim.x * CH_BLOCK) {
+        const int c = (int)(idx % C);
+        size_t t = idx / C;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const size_t n = t / Ho;
+        const float* b = x + ((n * H + 2 * oy) * W + 2 * ox) * C + c;
+        y[idx] = fmaxf(fmaxf(b[0], b[C]), fmaxf(b[(size_t)W * C], b[(size_t)W * C + C]));
+    }
+}
+
+// gradient goes to the FIRST maximum in (0,0),(0,1),(1,0),(1,1) order (ATen's max_pool2d tie rule);
+// pixels outside the pooled area (odd H/W) get zero
+__global__ __launch_bounds__(CH_BLOCK) void maxpool_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                               float* __restrict__ dx, int N, int H, int W, int C) {
+    const int Ho = H / 2, Wo = W / 2;
+    const size_t total = (size_t)N * H * W * C;
+    for (size_t idx = (size_t)blockIdx.x * CH_BLOCK + threadIdx.x; idx < total; idx += (size_t)gridDim.x * CH_BLOCK) {
+        const int c = (int)(idx % C);
+        size_t t = idx / C;
+        const int ix = (int)(t % W); t /= W;
+        const int iy = (int)(t % H);
+        const size_t n = t / H;
+        const int oy = iy / 2, ox = ix / 2;
+        float g = 0.f;
+        if (oy < Ho && ox < Wo) {
+            const float* b = x + ((n * H + 2 * oy) * W + 2 * ox) * C + c;
+            const float v[4] = {b[0], b[C], b[(size_t)W * C], b[(size_t)W * C + C]};
+            int am = 0;
+            for (int k = 1; k < 4; ++k)
+                if (v[k] > v[am]) am = k;
+            if (am == (iy & 1) * 2 + (ix & 1)) g = dy[((n * Ho + oy) * Wo + ox) * C + c];
+        }
+        dx[idx] = g;
+    }
+}
+
+// ---- loss gradients --------------------------------------------------------------------------------
+// d mean((a-b)^2) / da = 2 (a-b) / n * gout ; db = -da
+__global__ __launch_bounds__(CH_BLOCK) void mse_bwd_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                           const float* __restrict__ gout, size_t n,
+                                                           float* __restrict__ da, float* __restrict__ db) {
+    const float k = 2.f * gout[0] / (float)n;
+    for (size_t i = (size_t)blockIdx.x * CH_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * CH_BLOCK) {
+        const float g = (a[i] - b[i]) * k;
+        if (da) da[i] = g;
+        if (db) db[i] = -g;
+    }
+}
+
+// d BCE / dp = (p - t) / (max(p (1-p), 1e-12)) / n * gout   (ATen binary_cross_entropy_backward)
+__global__ __launch_bounds__(CH_BLOCK) void bce_bwd_kernel(const float* __restrict__ p, const float* __restrict__ t,
+                                                           const float* __restrict__ gout, size_t n,
+                                                           float* __restrict__ dp) {
+    const float k = gout[0] / (float)n;
+    for (size_t i = (size_t)blockIdx.x * CH_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * CH_BLOCK) {
+        const float pv = p[i];
+        dp[i] = k * (pv - t[i]) / fmaxf((1.f - pv) * pv, 1e-12f);
+    }
+}
+
+// ---- Adam (torch.optim.Adam defaults: no amsgrad, weight_decay 0; P/mode.py:90, :138-139) -------------
+__global__ __launch_bounds__(CH_BLOCK) void adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
+                                                        float* __restrict__ m, float* __restrict__ v, size_t n,
+                                                        float lr, float beta1, float beta2, float eps, float bc1,
+                                                        float bc2_sqrt) {
+    const float step_size = lr / bc1;
+    for (size_t i = (size_t)blockIdx.x * CH_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * CH_BLOCK) {
+        const float g = grad[i];
+        const float mi = m[i] + (g - m[i]) * (1.f - beta1);          // lerp, as torch
+        const float vi = v[i] * beta2 + (1.f - beta2) * g * g;
+        m[i] = mi; v[i] = vi;
+        const float denom = sqrtf(vi) / bc2_sqrt + eps;
+        param[i] -= step_size * (mi / denom);
+    }
+}
+
+// ---- host launchers ------------------------------------------------------------------------------------
+static unsigned ew_blocks(size_t total) {
+    size_t b = (total + CH_BLOCK - 1) / CH_BLOCK;
+    if (b > 8192) b = 8192;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+
+static dim3 ch_grid(long long M, int C) {
+    long long bx = (M + 63) / 64;  // >= 16 pixels per wave
+    if (bx > 512) bx = 512;
+    if (bx < 1) bx = 1;
+    return dim3((unsigned)bx, (unsigned)((C + 63) / 64));
+}
+
+int bn_train_stats(const float* z, long long M, int C, float eps, float momentum, float* mean, float* rstd,
+                   float* rmean, float* rvar, void* ws, hipStream_t s) {
+    int rc = hip_check(hipMemsetAsync(ws, 0, (size_t)2 * C * sizeof(double), s), "bn_stats memset");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_stats_kernel, ch_grid(M, C), dim3(CH_BLOCK), 0, s, z, M, C, (double*)ws);
+    rc = hip_check(hipGetLastError(), "bn_stats_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)ws, M, C, eps, momentum,
+                       mean, rstd, rmean, rvar);
+    return hip_check(hipGetLastError(), "bn_finalize_kernel");
+}
+
+static EpiParams epi_params(const srmi_epi_desc& d) {
+    EpiParams p;
+    memset(&p, 0, sizeof(p));
+    p.M = (long long)d.N * d.H * d.W;
+    p.H = d.H; p.W = d.W; p.C = d.C; p.r = d.shuffle; p.Cf = d.C / (d.shuffle * d.shuffle);
+    p.dcr = d.shuffle_order == SRMI_SHUFFLE_DCR;
+    p.act = d.act; p.act_param = d.act_param; p.alpha_pc = d.alpha_per_channel; p.bn = d.bn;
+    return p;
+}
+
+int epilogue_fwd(const srmi_epi_desc& d, const float* z, const float* mean, const float* rstd, const float* gamma,
+                 const float* beta, const float* alpha, const float* residual, float* y, hipStream_t s) {
+    EpiParams p = epi_params(d);
+    p.z = z; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.alpha = alpha; p.residual = residual;
+    p.y = y;
+    if (p.M == 0) return SRMI_OK;
+    hipLaunchKernelGGL(epilogue_fwd_kernel, dim3(ew_blocks((size_t)p.M * p.C)), dim3(CH_BLOCK), 0, s, p);
+    return hip_check(hipGetLastError(), "epilogue_fwd_kernel");
+}
+
+int epilogue_bwd(const srmi_epi_desc& d, const float* z, const float* dy, const float* mean, const float* rstd,
+                 const float* gamma, const float* beta, const float* alpha, float* dz, float* dsum1, float* dsum2,
+                 float* dalpha, void* ws, hipStream_t s) {
+    EpiParams p = epi_params(d);
+    p.z = z; p.dy = dy; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.alpha = alpha;
+    p.dz = dz; p.acc = (double*)ws;
+    const int n_alpha = d.act == SRMI_ACT_PRELU ? (d.alpha_per_channel ? p.Cf : 1) : 0;
+    int rc = hip_check(hipMemsetAsync(ws, 0, (size_t)3 * d.C * sizeof(double), s), "epilogue_bwd memset");
+    if (rc) return rc;
+    if (p.M > 0) {
+        hipLaunchKernelGGL(epilogue_bwd_kernel, ch_grid(p.M, p.C), dim3(CH_BLOCK), 0, s, p);
+        rc = hip_check(hipGetLastError(), "epilogue_bwd_kernel");
+        if (rc) return rc;
+        if (d.bn) {
+            hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks((size_t)p.M * p.C)), dim3(CH_BLOCK), 0, s, p);
+            rc = hip_check(hipGetLastError(), "bn_bwd_apply_kernel");
+            if (rc) return rc;
+        }
+    }
+    hipLaunchKernelGGL(epilogue_bwd_finalize_kernel, dim3((d.C + 255) / 256), dim3(256), 0, s, (const double*)ws, d.C,
+                       n_alpha, d.bn, dsum1, dsum2, dalpha);
+    return hip_check(hipGetLastError(), "epilogue_bwd_finalize_kernel");
+}
+
+int maxpool_fwd(const float* x, float* y, int N, int H, int W, int C, hipStream_t s) {
+    const size_t total = (size_t)N * (H / 2) * (W / 2) * C;
+    if (total == 0) return SRMI_OK;
+    hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(ew_blocks(total)), dim3(CH_BLOCK), 0, s, x, y, N, H, W, C);
+    return hip_check(hipGetLastError(), "maxpool_fwd_kernel");
+}
+
+int maxpool_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, hipStream_t s) {
+    const size_t total = (size_t)N * H * W * C;
+    if (total == 0) return SRMI_OK;
+    hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(ew_blocks(total)), dim3(CH_BLOCK), 0, s, x, dy, dx, N, H, W, C);
+    return hip_check(hipGetLastError(), "maxpool_bwd_kernel");
+}
+
+int mse_bwd(const float* a, const float* b, const float* gout, size_t n, float* da, float* db, hipStream_t s) {
+    if (n == 0) return SRMI_OK;
+    hipLaunchKernelGGL(mse_bwd_kernel, dim3(ew_blocks(n)), dim3(CH_BLOCK), 0, s, a, b, gout, n, da, db);
+    return hip_check(hipGetLastError(), "mse_bwd_kernel");
+}
+
+int bce_bwd(const float* p, const float* t, const float* gout, size_t n, float* dp, hipStream_t s) {
+    if (n == 0) return SRMI_OK;
+    hipLaunchKernelGGL(bce_bwd_kernel, dim3(ew_blocks(n)), dim3(CH_BLOCK), 0, s, p, t, gout, n, dp);
+    return hip_check(hipGetLastError(), "bce_bwd_kernel");
+}
+
+int adam_step(float* param, const float* grad, float* m, float* v, size_t n, float lr, float beta1, float beta2,
+              float eps, int step, hipStream_t s) {
+    if (n == 0) return SRMI_OK;
+    const double bc1 = 1.0 - pow((double)beta1, (double)step);
+    const double bc2 = 1.0 - pow((double)beta2, (double)step);
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(CH_BLOCK), 0, s, param, grad, m, v, n, lr, beta1, beta2, eps,
+                       (float)bc1, (float)sqrt(bc2));
+    return hip_check(hipGetLastError(), "adam_kernel");
+}
+
+}  // namespace srmi

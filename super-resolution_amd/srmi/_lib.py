@@ -59,6 +59,14 @@ class ConvArgs(C.Structure):
 CONV_FUSE_NEXT = 1
 
 
+class EpiDesc(C.Structure):
+    _fields_ = [
+        ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+        ("act", C.c_int32), ("act_param", C.c_float), ("alpha_per_channel", C.c_int32),
+        ("shuffle", C.c_int32), ("shuffle_order", C.c_int32), ("bn", C.c_int32),
+    ]
+
+
 # every symbol include/srmi.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "srmi_version": (C.c_int, []),
@@ -78,6 +86,22 @@ SYMBOLS = {
                                C.c_void_p, C.c_void_p]),
     "srmi_y_psnr_ssim": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "srmi_train_workspace_bytes": (C.c_int, [C.c_int32, C.POINTER(C.c_size_t)]),
+    "srmi_bn_train_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
+                                      C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "srmi_epilogue_fwd": (C.c_int, [C.POINTER(EpiDesc)] + [C.c_void_p] * 9),
+    "srmi_epilogue_bwd": (C.c_int, [C.POINTER(EpiDesc)] + [C.c_void_p] * 13),
+    "srmi_conv2d_dgrad_packed_weight_bytes": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_size_t)]),
+    "srmi_conv2d_dgrad_pack_weights": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
+    "srmi_conv2d_dgrad": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "srmi_conv2d_wgrad": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "srmi_maxpool2x2_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "srmi_maxpool2x2_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_void_p]),
+    "srmi_mse_loss_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "srmi_bce_loss_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "srmi_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float,
+                                 C.c_float, C.c_float, C.c_int32, C.c_void_p]),
 }
 REDUCE_WS_BYTES = 16384
 

@@ -1,0 +1,237 @@
+"""Training path: ``torch.autograd.Function``s over the C ABI (SURVEY 8 b1 "what calls the boundary").
+
+One Function per fused op - conv (+bias) -> [train-mode BatchNorm] -> [activation] -> [sub-pixel
+store] -> [+ residual] - so ``loss.backward()`` and ``optim.Adam(model.parameters())`` of the
+reference loops (P/mode.py:96-106, :141-179) run unmodified.  Everything between the user's NCHW
+tensors is fp32 NHWC on the device (tensors carry ``torch.channels_last`` strides, so their logical
+shape stays NCHW); all arithmetic is in libsrmi's kernels:
+
+  forward   z = conv(x)+b      srmi_conv2d_fwd (exact-f32 MFMA kernel)
+            batch stats         srmi_bn_train_stats (also updates running_mean / running_var)
+            y = act(bn(z)) (+r) srmi_epilogue_fwd
+  backward  dz, dgamma, dbeta,  srmi_epilogue_bwd
+            dalpha, dbias
+            dW                  srmi_conv2d_wgrad
+            dx                  srmi_conv2d_dgrad
+
+There is no fallback to ATen convolution / batch-norm kernels anywhere in this file.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+import torch.nn as nn
+from torch.autograd.function import once_differentiable
+
+from . import _lib as L
+from . import functional as Fn
+
+_CL = torch.channels_last
+_ONES = {}
+
+
+def _ones(n, device):
+    key = (device, n)
+    t = _ONES.get(key)
+    if t is None:
+        t = _ONES[key] = torch.ones(n, dtype=torch.float32, device=device)
+    return t
+
+
+def nhwc(x: torch.Tensor) -> torch.Tensor:
+    """Logical NCHW tensor whose storage is dense NHWC f32 (converted by srmi_layout_convert if needed)."""
+    Fn.require_cuda(x)
+    if x.dtype != torch.float32:
+        raise TypeError(f"srmi training path is fp32, got {x.dtype}")
+    if x.is_contiguous(memory_format=_CL):
+        return x
+    x = x.contiguous()
+    N, Cc, H, W = x.shape
+    out = torch.empty_like(x, memory_format=_CL)
+    if x.numel():
+        L.check(L.load().srmi_layout_convert(x.data_ptr(), out.data_ptr(), N, Cc, H, W, L.NCHW, L.F32, L.NHWC, L.F32,
+                                             Fn.stream_ptr()))
+    return out
+
+
+def nchw(x: torch.Tensor) -> torch.Tensor:
+    """Dense NCHW copy of a channels_last tensor (module edge, e.g. the SR image handed back to the user)."""
+    if x.is_contiguous():
+        return x
+    x = nhwc(x)
+    N, Cc, H, W = x.shape
+    out = torch.empty((N, Cc, H, W), dtype=torch.float32, device=x.device)
+    if x.numel():
+        L.check(L.load().srmi_layout_convert(x.data_ptr(), out.data_ptr(), N, Cc, H, W, L.NHWC, L.F32, L.NCHW, L.F32,
+                                             Fn.stream_ptr()))
+    return out
+
+
+def _empty_cl(shape, device):
+    return torch.empty(shape, dtype=torch.float32, device=device, memory_format=_CL)
+
+
+def _ptr(t):
+    return t.data_ptr() if t is not None else None
+
+
+class _Cfg:
+    """static (non-tensor) configuration of one fused op"""
+
+    __slots__ = ("stride", "pad", "act", "act_param", "apc", "shuffle", "order", "bn")
+
+    def __init__(self, stride, pad, act, act_param, apc, shuffle, order, bn):
+        self.stride, self.pad, self.act, self.act_param, self.apc = stride, pad, act, act_param, apc
+        self.shuffle, self.order, self.bn = shuffle, order, bn
+
+
+class FusedConvFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, alpha, residual, cfg: _Cfg):
+        lib = L.load()
+        st = Fn.stream_ptr()
+        x = nhwc(x)
+        dev = x.device
+        N, Cin, H, W = x.shape
+        Cout, _, kh, kw = weight.shape
+        desc = Fn.make_desc(N, H, W, Cin, Cout, (kh, kw), stride=cfg.stride, pad=cfg.pad, compute=L.COMPUTE_F32)
+        _, _, Ho, Wo = Fn.out_shape(desc)
+        w = weight.detach().contiguous()
+        wp = Fn.pack_weights(desc, w)
+        shift = bias.detach().contiguous() if bias is not None else torch.zeros(Cout, device=dev)
+        z = _empty_cl((N, Cout, Ho, Wo), dev)
+        Fn.conv2d_fused(desc, x, wp, _ones(Cout, dev), shift, out=z)
+
+        bn = cfg.bn
+        mean = rstd = None
+        M = N * Ho * Wo
+        if bn is not None:
+            if M == 0:
+                raise ValueError("srmi: train-mode BatchNorm over an empty batch")
+            mean = torch.empty(Cout, dtype=torch.float32, device=dev)
+            rstd = torch.empty(Cout, dtype=torch.float32, device=dev)
+            ws = torch.empty(3 * Cout, dtype=torch.float64, device=dev)
+            track = bn.track_running_stats and bn.running_mean is not None
+            if bn.momentum is None:
+                raise NotImplementedError("srmi: BatchNorm2d(momentum=None) (cumulative average) is not supported")
+            L.check(lib.srmi_bn_train_stats(z.data_ptr(), M, Cout, float(bn.eps), float(bn.momentum), mean.data_ptr(),
+                                            rstd.data_ptr(), _ptr(bn.running_mean) if track else None,
+                                            _ptr(bn.running_var) if track else None, ws.data_ptr(), st))
+            if track and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked.add_(1)
+        r = cfg.shuffle
+        ed = L.EpiDesc(N, Ho, Wo, Cout, cfg.act, cfg.act_param, cfg.apc, r, cfg.order, int(bn is not None))
+        y = _empty_cl((N, Cout // (r * r), Ho * r, Wo * r), dev)
+        res = nhwc(residual) if residual is not None else None
+        if res is not None and res.shape != y.shape:
+            raise ValueError(f"srmi: residual shape {tuple(res.shape)} != output shape {tuple(y.shape)}")
+        a = alpha.detach().contiguous() if alpha is not None else None
+        g_ = gamma.detach().contiguous() if gamma is not None else None
+        b_ = beta.detach().contiguous() if beta is not None else None
+        L.check(lib.srmi_epilogue_fwd(C.byref(ed), z.data_ptr(), _ptr(mean), _ptr(rstd), _ptr(g_), _ptr(b_), _ptr(a),
+                                      _ptr(res), y.data_ptr(), st))
+        ctx.save_for_backward(x, w, z, mean, rstd, g_, b_, a)
+        ctx.cfg, ctx.desc, ctx.ed = cfg, desc, ed
+        ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        lib = L.load()
+        st = Fn.stream_ptr()
+        x, w, z, mean, rstd, gamma, beta, alpha = ctx.saved_tensors
+        cfg, desc, ed = ctx.cfg, ctx.desc, ctx.ed
+        dev = x.device
+        dy = nhwc(dy)
+        Cout = desc.Cout
+        dz = torch.empty_like(z)
+        ws = torch.empty(3 * Cout, dtype=torch.float64, device=dev)
+        dsum1 = torch.empty(Cout, dtype=torch.float32, device=dev)
+        dsum2 = torch.empty(Cout, dtype=torch.float32, device=dev) if cfg.bn is not None else None
+        dalpha = torch.empty_like(alpha) if alpha is not None else None
+        L.check(lib.srmi_epilogue_bwd(C.byref(ed), z.data_ptr(), dy.data_ptr(), _ptr(mean), _ptr(rstd), _ptr(gamma),
+                                      _ptr(beta), _ptr(alpha), dz.data_ptr(), dsum1.data_ptr(), _ptr(dsum2),
+                                      _ptr(dalpha), ws.data_ptr(), st))
+        need = ctx.needs_input_grad
+        dx = dw = dbias = dgamma = dbeta = None
+        if need[1]:
+            dw = torch.empty_like(w)
+            L.check(lib.srmi_conv2d_wgrad(C.byref(desc), x.data_ptr(), dz.data_ptr(), dw.data_ptr(), st))
+        if need[0]:
+            nbytes = C.c_size_t(0)
+            L.check(lib.srmi_conv2d_dgrad_packed_weight_bytes(C.byref(desc), C.byref(nbytes)))
+            wd = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+            L.check(lib.srmi_conv2d_dgrad_pack_weights(C.byref(desc), w.data_ptr(), wd.data_ptr(), st))
+            dx = torch.empty_like(x)
+            L.check(lib.srmi_conv2d_dgrad(C.byref(desc), dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), st))
+        if cfg.bn is not None:
+            dgamma, dbeta = dsum2, dsum1
+            # the bias of a conv feeding train-mode BN has an exactly-zero gradient (BN removes the mean)
+            dbias = torch.zeros(Cout, dtype=torch.float32, device=dev) if ctx.has_bias else None
+        else:
+            dbias = dsum1 if ctx.has_bias else None
+        return dx, dw, dbias, dgamma, dbeta, dalpha if need[5] else None, dy if ctx.has_res else None, None
+
+
+def fused_conv(x, c2d: nn.Conv2d, bn, act, residual=None, shuffle=1, shuffle_order=L.SHUFFLE_CRD, weight=None, pad=None):
+    """conv -> [BN (train)] -> [act] -> [shuffle] -> [+residual] through FusedConvFn.
+    `weight` overrides c2d.weight (a differentiable view, e.g. nn.Linear's weight as OIHW)."""
+    code, param, alpha, apc = Fn.act_of(act)
+    if bn is not None and not bn.training:
+        raise NotImplementedError("srmi: autograd through eval-mode BatchNorm is not supported - call .train() "
+                                  "(the reference trains with train-mode BN, P/mode.py:101) or use torch.no_grad()")
+    cfg = _Cfg(c2d.stride[0] if c2d is not None else 1,
+               pad if pad is not None else c2d.padding[0], code, param, apc, shuffle, shuffle_order, bn)
+    w = weight if weight is not None else c2d.weight
+    b = c2d.bias if c2d is not None else None
+    return FusedConvFn.apply(x, w, b, bn.weight if bn is not None else None, bn.bias if bn is not None else None,
+                             alpha, residual, cfg)
+
+
+def linear(x, lin: nn.Linear, act=None):
+    """nn.Linear on the NCHW-flattened feature map (P/srgan_model.py:69-71) = a conv whose kernel covers the
+    whole map: weight [out, C*H*W] viewed as OIHW [out, C, H, W], no padding -> [N, out, 1, 1]."""
+    N, Cc, H, W = x.shape
+    if lin.in_features != Cc * H * W:
+        raise ValueError(f"srmi: Linear expects {lin.in_features} features, got {Cc}x{H}x{W}")
+    code, param, alpha, apc = Fn.act_of(act)
+    cfg = _Cfg(1, 0, code, param, apc, 1, L.SHUFFLE_CRD, None)
+    return FusedConvFn.apply(x, lin.weight.view(lin.out_features, Cc, H, W), lin.bias, None, None, alpha, None, cfg)
+
+
+class MaxPool2x2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = nhwc(x)
+        N, Cc, H, W = x.shape
+        y = _empty_cl((N, Cc, H // 2, W // 2), x.device)
+        L.check(L.load().srmi_maxpool2x2_fwd(x.data_ptr(), y.data_ptr(), N, H, W, Cc, Fn.stream_ptr()))
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = nhwc(dy)
+        N, Cc, H, W = x.shape
+        dx = torch.empty_like(x)
+        L.check(L.load().srmi_maxpool2x2_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), N, H, W, Cc, Fn.stream_ptr()))
+        return dx
+
+
+def maxpool2x2(x):
+    return MaxPool2x2Fn.apply(x)
+
+
+def wants_training_path(x, *modules):
+    """True when the call needs the training kernels: autograd is recording, or a BatchNorm is in train mode."""
+    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for m in modules for p in m.parameters())):
+        return True
+    for m in modules:
+        for sub in m.modules():
+            if isinstance(sub, nn.BatchNorm2d) and sub.training:
+                return True
+    return False

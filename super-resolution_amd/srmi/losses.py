@@ -1,8 +1,8 @@
 """Loss reductions of the SRGAN step on the HIP kernels (csrc/metrics.hip).
 
 Mirrors the reference's call sites: ``nn.MSELoss`` (P/mode.py:89, :169), ``nn.BCELoss``
-(P/mode.py:136), ``TVLoss`` (P/losses.py:41-59).  Forward values only (inference / logging); results
-stay on the device as 0-d float32 tensors, no host synchronisation.  No CPU fallback.
+(P/mode.py:136), ``TVLoss`` (P/losses.py:41-59).  Results stay on the device as 0-d float32 tensors, no
+host synchronisation; MSE and BCE are differentiable (HIP backward kernels).  No CPU fallback.
 """
 from __future__ import annotations
 
@@ -29,26 +29,77 @@ def _f32c(t, what):
     return t.contiguous()
 
 
+def _same_storage_order(a, b):
+    """Both operands as dense tensors in ONE common element order (a mean over elements does not care
+    which): 4-D tensors go to NHWC storage (what the training path produces), others to row-major."""
+    if a.dim() == 4:
+        from .autograd import nhwc
+        for t, w in ((a, "input"), (b, "target")):
+            _f32c_check(t, w)
+        return nhwc(a), nhwc(b)
+    return _f32c(a, "input"), _f32c(b, "target")
+
+
+def _f32c_check(t, what):
+    require_cuda(t, what)
+    if t.dtype != torch.float32:
+        raise TypeError(f"srmi: {what} must be float32, got {t.dtype}")
+
+
+class _MSEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = _same_storage_order(a, b)
+        out = torch.empty((), dtype=torch.float32, device=a.device)
+        L.check(L.load().srmi_mse_loss(a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(),
+                                       _workspace(a.device).data_ptr(), stream_ptr()))
+        ctx.save_for_backward(a, b)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        a, b = ctx.saved_tensors
+        g = g.contiguous()
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        if da is not None or db is not None:
+            L.check(L.load().srmi_mse_loss_bwd(a.data_ptr(), b.data_ptr(), g.data_ptr(), a.numel(),
+                                               da.data_ptr() if da is not None else None,
+                                               db.data_ptr() if db is not None else None, stream_ptr()))
+        return da, db
+
+
+class _BCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, p, t):
+        p, t = _f32c(p, "input"), _f32c(t, "target")
+        out = torch.empty((), dtype=torch.float32, device=p.device)
+        L.check(L.load().srmi_bce_loss(p.data_ptr(), t.data_ptr(), p.numel(), out.data_ptr(),
+                                       _workspace(p.device).data_ptr(), stream_ptr()))
+        ctx.save_for_backward(p, t)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        p, t = ctx.saved_tensors
+        dp = torch.empty_like(p)
+        L.check(L.load().srmi_bce_loss_bwd(p.data_ptr(), t.data_ptr(), g.contiguous().data_ptr(), p.numel(),
+                                           dp.data_ptr(), stream_ptr()))
+        return dp, None
+
+
 def mse_loss(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """``nn.MSELoss()(a, b)`` (mean reduction)."""
+    """``nn.MSELoss()(a, b)`` (mean reduction), differentiable w.r.t. both operands."""
     if a.shape != b.shape:
         raise ValueError(f"srmi.mse_loss: shapes differ {tuple(a.shape)} vs {tuple(b.shape)}")
-    a, b = _f32c(a, "input"), _f32c(b, "target")
-    out = torch.empty((), dtype=torch.float32, device=a.device)
-    L.check(L.load().srmi_mse_loss(a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(),
-                                   _workspace(a.device).data_ptr(), stream_ptr()))
-    return out
+    return _MSEFn.apply(a, b)
 
 
 def bce_loss(p: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
-    """``nn.BCELoss()(p, t)`` (mean reduction, logs clamped at -100 like torch)."""
+    """``nn.BCELoss()(p, t)`` (mean reduction, logs clamped at -100 like torch), differentiable w.r.t. p."""
     if p.shape != t.shape:
         raise ValueError(f"srmi.bce_loss: shapes differ {tuple(p.shape)} vs {tuple(t.shape)}")
-    p, t = _f32c(p, "input"), _f32c(t, "target")
-    out = torch.empty((), dtype=torch.float32, device=p.device)
-    L.check(L.load().srmi_bce_loss(p.data_ptr(), t.data_ptr(), p.numel(), out.data_ptr(),
-                                   _workspace(p.device).data_ptr(), stream_ptr()))
-    return out
+    return _BCEFn.apply(p, t)
 
 
 class MSELoss(nn.Module):

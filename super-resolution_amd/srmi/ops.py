@@ -8,8 +8,10 @@ running the Sequential through ATen, each block issues ONE fused launch (conv + 
 activation [+ residual] [+ PixelShuffle store]).  Whole-network forwards go through the plans in
 ``engine.py``; the per-block forwards below serve users who call a block on its own.
 
-No fallback: CPU tensors, autograd and train-mode BatchNorm raise (the training kernels are a later
-milestone - DESIGN.md "Out of scope this round").
+Training (autograd recording, or a BatchNorm in train mode) routes every block through
+``autograd.FusedConvFn`` - fp32 conv / train-BN / epilogue / dgrad / wgrad kernels of the same library.
+
+No fallback: CPU tensors raise; nothing here calls an ATen convolution or batch-norm kernel.
 """
 from __future__ import annotations
 
@@ -17,6 +19,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
+from . import autograd as AG
 from . import functional as Fn
 from .engine import _sig, conv_parts
 
@@ -36,15 +39,10 @@ class _conv(nn.Conv2d):
 
 
 def _guard(x, *modules):
+    """Device check; returns True when the call must take the training kernels (autograd recording or a
+    BatchNorm in train mode), False for the inference plans."""
     Fn.require_cuda(x)
-    if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for m in modules for p in m.parameters())):
-        raise NotImplementedError(
-            "srmi: the autograd (training) path is not built yet - call under torch.no_grad(); "
-            "the inference forward is the HIP path of this round")
-    for m in modules:
-        for sub in m.modules():
-            if isinstance(sub, nn.BatchNorm2d) and sub.training:
-                raise NotImplementedError("srmi: train-mode BatchNorm is not built yet - call .eval() first")
+    return AG.wants_training_path(x, *modules)
 
 
 class _FusedCache:
@@ -105,8 +103,9 @@ class conv(nn.Module):
         self._cache = _FusedCache()
 
     def forward(self, x, _residual=None):
-        _guard(x, self)
         c2d, bn, act = conv_parts(self)
+        if _guard(x, self):
+            return AG.fused_conv(x, c2d, bn, act, residual=_residual)
         return _run_block(self, self._cache, c2d, bn, act, x, residual=_residual)
 
 
@@ -119,7 +118,7 @@ class ResBlock(nn.Module):
                                   conv(channels, channels, kernel_size, BN=True, act=None))
 
     def forward(self, x):
-        _guard(x, self)
+        Fn.require_cuda(x)
         return self.body[1](self.body[0](x), _residual=x)
 
 
@@ -134,7 +133,7 @@ class BasicBlock(nn.Module):
         self.body = nn.Sequential(*m)
 
     def forward(self, x):
-        _guard(x, self)
+        Fn.require_cuda(x)
         res = self.conv(x)
         out = res
         for blk in list(self.body)[:-1]:
@@ -155,9 +154,10 @@ class Upsampler(nn.Module):
         self._cache = _FusedCache()
 
     def forward(self, x):
-        _guard(x, self)
         c2d = self.body[0].body[0]
         act = self.body[2] if len(self.body) > 2 else None
+        if _guard(x, self):
+            return AG.fused_conv(x, c2d, None, act, shuffle=self.body[1].upscale_factor)
         if isinstance(act, nn.PReLU) and act.weight.numel() > 1:
             raise NotImplementedError("srmi: per-channel PReLU after PixelShuffle")
         return _run_block(self, self._cache, c2d, None, act, x, shuffle=self.body[1].upscale_factor)
@@ -172,5 +172,5 @@ class discrim_block(nn.Module):
                                   conv(out_feats, out_feats, kernel_size, BN=True, act=act, stride=2))
 
     def forward(self, x):
-        _guard(x, self)
+        Fn.require_cuda(x)
         return self.body[1](self.body[0](x))

@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib as L
+from . import autograd as AG
 from .engine import DiscriminatorPlan, GeneratorPlan, PlanCache
 from .ops import Upsampler, ResBlock, _guard, conv, discrim_block
 
@@ -57,9 +58,18 @@ class Generator(nn.Module, _ComputeMixin):
         self._plans = PlanCache(GeneratorPlan)
 
     def forward(self, x):
-        _guard(x, self)
         if x.dim() != 4:
             raise ValueError(f"Generator expects NCHW input, got shape {tuple(x.shape)}")
+        if _guard(x, self):
+            # training step (P/mode.py:101, :149, :164): the reference's forward, block by block, on the
+            # fp32 training kernels; tensors are logical NCHW with channels_last (NHWC) storage
+            x = self.conv01(x)
+            _skip_connection = x
+            x = self.body(x)
+            feat = self.conv02(x, _residual=_skip_connection)
+            x = self.tail(feat)
+            x = self.last_conv(x)
+            return x, feat
         N, _, H, W = x.shape
         plan = self._plans.get(self, N, H, W, _COMPUTE[self.compute])
         return plan.run(x)
@@ -79,7 +89,13 @@ class Discriminator(nn.Module, _ComputeMixin):
         self._plans = PlanCache(DiscriminatorPlan)
 
     def forward(self, x):
-        _guard(x, self)
+        if _guard(x, self):
+            x = self.conv01(x)
+            x = self.conv02(x)
+            x = self.body(x)
+            x = AG.linear(x, self.tail[0], self.tail[1])       # flatten (NCHW order) + Linear + act
+            x = AG.linear(x, self.tail[2], self.tail[3])       # Linear + Sigmoid
+            return x.reshape(x.size(0), -1)
         N, _, H, W = x.shape
         plan = self._plans.get(self, N, H, W, _COMPUTE[self.compute])
         return plan.run(x)

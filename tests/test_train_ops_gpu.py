@@ -1,0 +1,185 @@
+"""GPU: the training kernels (train-mode BN, epilogue fwd/bwd, dgrad, wgrad, max-pool, loss grads, Adam)
+through the C ABI via srmi.autograd, against oracle/train_oracle.py (torch CPU ops + torch autograd, the
+arithmetic the reference itself runs).  fp32: values <=1e-4 abs on O(1) data, gradients <=2e-4 relative
+to the gradient's max magnitude."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import train_oracle as T
+from srmi import _lib as L
+from srmi import autograd as AG
+from srmi import losses
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+ACTS = {"none": (L.ACT_NONE, None), "prelu": (L.ACT_PRELU, None), "lrelu": (L.ACT_LRELU, None),
+        "relu": (L.ACT_RELU, None), "tanh": (L.ACT_TANH, None), "sigmoid": (L.ACT_SIGMOID, None)}
+
+
+def _close(got, ref, tol=2e-4, what=""):
+    ref = ref.detach().double()
+    got = got.detach().double().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = max(1.0, float(ref.abs().max())) if ref.numel() else 1.0
+    err = float((got - ref).abs().max()) if ref.numel() else 0.0
+    assert err <= tol * scale, f"{what}: max|d|={err:.3e} scale={scale:.3e}"
+
+
+CASES = [
+    # N, H, W, Cin, Cout, k, stride, bn, act, shuffle, dcr, residual, alpha_pc
+    (2, 8, 8, 3, 64, 9, 1, False, "prelu", 1, False, False, False),     # G conv01
+    (2, 8, 8, 64, 64, 3, 1, True, "prelu", 1, False, False, False),     # ResBlock conv1
+    (2, 8, 8, 64, 64, 3, 1, True, "none", 1, False, True, False),       # ResBlock conv2 + skip
+    (2, 6, 5, 64, 256, 3, 1, False, "prelu", 2, False, False, False),   # Upsampler (CRD)
+    (1, 5, 7, 32, 36, 3, 1, False, "prelu", 3, False, False, False),    # Upsampler scale 3
+    (2, 6, 6, 16, 64, 3, 1, False, "prelu", 2, True, False, True),      # Keras: DCR + per-channel PReLU
+    (2, 12, 12, 64, 3, 3, 1, False, "tanh", 1, False, False, False),    # G last_conv
+    (3, 16, 16, 3, 64, 3, 1, False, "lrelu", 1, False, False, False),   # D conv01
+    (3, 16, 16, 64, 64, 3, 2, False, "lrelu", 1, False, False, False),  # D conv02 stride 2
+    (3, 9, 11, 64, 128, 3, 2, True, "lrelu", 1, False, False, False),   # discrim_block stride 2 + BN, odd size
+    (2, 8, 8, 64, 128, 3, 1, False, "relu", 1, False, False, False),    # VGG conv + ReLU
+    (4, 1, 1, 40, 1, 1, 1, False, "sigmoid", 1, False, False, False),   # Linear + Sigmoid
+    (2, 7, 7, 5, 20, 5, 1, True, "relu", 1, False, True, False),        # odd channels, 5x5
+]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[str(i) for i in range(len(CASES))])
+def test_fused_conv_forward_backward(case):
+    N, H, W, Cin, Cout, k, stride, bn, act, r, dcr, has_res, apc = case
+    g = torch.Generator().manual_seed(hash(case) % (2 ** 31))
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (1.5 / (Cin * k * k) ** 0.5)
+    b = torch.randn(Cout, generator=g) * 0.2
+    gamma = torch.rand(Cout, generator=g) + 0.5 if bn else None
+    beta = torch.randn(Cout, generator=g) * 0.2 if bn else None
+    Cf = Cout // (r * r)
+    alpha = (torch.rand(Cf if apc else 1, generator=g) * 0.4 + 0.05) if act == "prelu" else None
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    res = torch.randn(N, Cf, Ho * r, Wo * r, generator=g) if has_res else None
+    gy = torch.randn(N, Cf, Ho * r, Wo * r, generator=g)
+    rm0, rv0 = torch.randn(Cout, generator=g) * 0.1, torch.rand(Cout, generator=g) + 0.5
+
+    # oracle (CPU, autograd)
+    leaves = {n: t.clone().requires_grad_(True) for n, t in
+              dict(x=x, w=w, b=b, gamma=gamma, beta=beta, alpha=alpha, res=res).items() if t is not None}
+    rm, rv = rm0.clone(), rv0.clone()
+    y_ref = T.fused_conv(leaves["x"], leaves["w"], leaves["b"], leaves.get("gamma"), leaves.get("beta"),
+                         leaves.get("alpha"), leaves.get("res"), stride=stride, act=act, slope=0.01, shuffle=r,
+                         dcr=dcr, running=(rm, rv) if bn else None)
+    y_ref.backward(gy)
+
+    # device
+    c2d = nn.Conv2d(Cin, Cout, k, stride=stride, padding=k // 2).to(DEV)
+    bnm = nn.BatchNorm2d(Cout).to(DEV).train() if bn else None
+    with torch.no_grad():
+        c2d.weight.copy_(w); c2d.bias.copy_(b)
+        if bn:
+            bnm.weight.copy_(gamma); bnm.bias.copy_(beta); bnm.running_mean.copy_(rm0); bnm.running_var.copy_(rv0)
+    actm = {"none": None, "prelu": nn.PReLU(Cf if apc else 1), "lrelu": nn.LeakyReLU(), "relu": nn.ReLU(),
+            "tanh": nn.Tanh(), "sigmoid": nn.Sigmoid()}[act]
+    if act == "prelu":
+        actm = actm.to(DEV)
+        with torch.no_grad():
+            actm.weight.copy_(alpha)
+    xd = x.to(DEV).requires_grad_(True)
+    resd = res.to(DEV).requires_grad_(True) if has_res else None
+    y = AG.fused_conv(xd, c2d, bnm, actm, residual=resd, shuffle=r,
+                      shuffle_order=L.SHUFFLE_DCR if dcr else L.SHUFFLE_CRD)
+    assert y.shape == y_ref.shape
+    _close(y, y_ref, 1e-4, "y")
+    y.backward(gy.to(DEV))
+    _close(xd.grad, leaves["x"].grad, what="dx")
+    _close(c2d.weight.grad, leaves["w"].grad, what="dw")
+    if bn:
+        _close(bnm.weight.grad, leaves["gamma"].grad, what="dgamma")
+        _close(bnm.bias.grad, leaves["beta"].grad, what="dbeta")
+        _close(bnm.running_mean, rm, 1e-5, "running_mean")
+        _close(bnm.running_var, rv, 1e-5, "running_var")
+        assert int(bnm.num_batches_tracked) == 1
+        assert float(c2d.bias.grad.abs().max()) == 0.0 and float(leaves["b"].grad.abs().max()) < 1e-4
+    else:
+        _close(c2d.bias.grad, leaves["b"].grad, what="dbias")
+    if act == "prelu":
+        _close(actm.weight.grad, leaves["alpha"].grad, what="dalpha")
+    if has_res:
+        _close(resd.grad, leaves["res"].grad, what="dres")
+
+
+def test_linear_as_full_map_conv():
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(3, 8, 3, 3, generator=g)
+    lin = nn.Linear(72, 10)
+    xr = x.clone().requires_grad_(True)
+    ref = torch.nn.functional.leaky_relu(lin(xr.view(3, -1)), 0.01)
+    ref.sum().backward()
+    lind = nn.Linear(72, 10).to(DEV)
+    lind.load_state_dict(lin.state_dict())
+    xd = x.to(DEV).requires_grad_(True)
+    y = AG.linear(xd, lind, nn.LeakyReLU())
+    assert y.shape == (3, 10, 1, 1)
+    _close(y.reshape(3, 10), ref, 1e-5, "linear")
+    y.sum().backward()
+    _close(lind.weight.grad, lin.weight.grad, what="dW")
+    _close(lind.bias.grad, lin.bias.grad, what="db")
+    _close(xd.grad, xr.grad, what="dx")
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 6, 6), (1, 3, 7, 9), (2, 64, 24, 24)])
+def test_maxpool2x2(shape):
+    g = torch.Generator().manual_seed(sum(shape))
+    x = torch.randn(shape, generator=g)
+    x[0, 0, 0, 0] = x[0, 0, 0, 1] = x[0, 0, 1, 0] = x[0, 0, 1, 1] = 2.5          # tie: first maximum takes the gradient
+    xr = x.clone().requires_grad_(True)
+    ref = torch.nn.functional.max_pool2d(xr, 2, 2)
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    xd = x.to(DEV).requires_grad_(True)
+    y = AG.maxpool2x2(xd)
+    _close(y, ref, 0.0, "pool")
+    y.backward(gy.to(DEV))
+    _close(xd.grad, xr.grad, 0.0, "dpool")
+
+
+def test_loss_gradients():
+    g = torch.Generator().manual_seed(4)
+    a, b = torch.randn(2, 3, 8, 10, generator=g), torch.randn(2, 3, 8, 10, generator=g)
+    ar = a.clone().requires_grad_(True)
+    (torch.nn.functional.mse_loss(ar, b) * 3).backward()
+    ad = a.to(DEV).requires_grad_(True)
+    bd = b.to(DEV).to(memory_format=torch.channels_last)          # mixed storage orders
+    (losses.MSELoss()(ad, bd) * 3).backward()
+    _close(ad.grad, ar.grad, 1e-6, "dmse")
+    p = torch.rand(16, 1, generator=g) * 0.98 + 0.01
+    for t in (torch.ones(16, 1), torch.zeros(16, 1)):
+        pr = p.clone().requires_grad_(True)
+        torch.nn.functional.binary_cross_entropy(pr, t).backward()
+        pd = p.to(DEV).requires_grad_(True)
+        losses.BCELoss()(pd, t.to(DEV)).backward()
+        _close(pd.grad, pr.grad, 1e-5, "dbce")
+
+
+def test_adam_step_matches_torch():
+    g = torch.Generator().manual_seed(8)
+    p0 = torch.randn(1000, generator=g)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-4)
+    pd = p0.to(DEV)
+    m = torch.zeros_like(pd); v = torch.zeros_like(pd)
+    for step in range(1, 4):
+        gr = torch.randn(1000, generator=g)
+        pr.grad = gr.clone()
+        opt.step()
+        gd = gr.to(DEV)
+        L.check(L.load().srmi_adam_step(pd.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), 1000, 1e-4, 0.9, 0.999,
+                                        1e-8, step, 0))
+        assert float((pd.cpu() - pr.detach()).abs().max()) <= 1e-7
+
+
+def test_eval_bn_under_autograd_is_rejected():
+    c2d = nn.Conv2d(4, 4, 3, padding=1).to(DEV)
+    bn = nn.BatchNorm2d(4).to(DEV).eval()
+    with pytest.raises(NotImplementedError):
+        AG.fused_conv(torch.zeros(1, 4, 4, 4, device=DEV), c2d, bn, None)
