@@ -115,6 +115,70 @@ def gen_train_case(fname, num_block, shape, wseed=0, xseed=3):
     np.savez_compressed(os.path.join(GOLD, fname), **out)
 
 
+def _summ(t, stride=37):
+    """full tensor when small, else fp64 moments + a strided sample (same recipe on the test side)."""
+    t = t.detach()
+    flat = t.reshape(-1)
+    return dict(sum=flat.double().sum().item(), sumsq=(flat.double() ** 2).sum().item(),
+                absmax=flat.abs().max().item() if flat.numel() else 0.0, sample=flat[::stride].clone().numpy())
+
+
+def pretrain_step_case(fname, n_feats, num_block, shape, full, wseed=0, xseed=21, steps=2):
+    """`train()` phase 1 (P/mode.py:96-106): generator(lr) in train mode -> MSELoss(gt, output) ->
+    g_optim.zero_grad(); loss.backward(); g_optim.step(), Adam(lr=1e-4) (P/mode.py:90), run by the REFERENCE
+    Generator.  Stores the loss, every parameter gradient of step 1, and parameters / BN buffers after `steps`."""
+    print(fname)
+    np_sd = W.generator_weights(seed=wseed, num_block=num_block, n_feats=n_feats)
+    sd = O.to_torch(np_sd)
+    g = Generator(n_feats=n_feats, num_block=num_block)
+    g.load_state_dict(sd, strict=True)
+    g.train()
+    lr = torch.from_numpy(W.lr_input(shape, seed=xseed))
+    gt = torch.from_numpy(W.lr_input((shape[0], 3, shape[2] * 4, shape[3] * 4), seed=xseed + 1))
+    l2 = torch.nn.MSELoss()
+    opt = torch.optim.Adam(g.parameters(), lr=1e-4)
+    out = dict(n_feats=n_feats, num_block=num_block, wseed=wseed, xseed=xseed, shape=np.array(shape), steps=steps,
+               full=int(full))
+    losses_ = []
+    for it in range(steps):
+        output, _ = g(lr)
+        loss = l2(gt, output)
+        opt.zero_grad()
+        loss.backward()
+        if it == 0:
+            # oracle: same forward restated functionally, gradients by torch autograd
+            leaves = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+                      for k, v in sd.items()}
+            shared = leaves["conv01.body.1.weight"]
+            for k in leaves:
+                if k.endswith(".weight") and leaves[k].shape == (1,) and k != "conv01.body.1.weight":
+                    leaves[k] = shared
+            osr, _ = O.generator_forward(leaves, lr, num_block=num_block, training=True, stats_out={})
+            oloss = torch.nn.functional.mse_loss(osr, gt)
+            oloss.backward()
+            _check("loss", loss.detach(), oloss.detach(), tol=1e-6)
+            for name, p in g.named_parameters():
+                ref_g = leaves[name].grad
+                tol = 1e-5 * max(1.0, p.grad.abs().max().item())
+                _check("grad " + name[-26:], p.grad, ref_g, tol=tol)
+                if full:
+                    out["grad:" + name] = p.grad.numpy().copy()
+                else:
+                    for kk, vv in _summ(p.grad).items():
+                        out[f"grad_{kk}:" + name] = vv
+        opt.step()
+        losses_.append(loss.item())
+    out["loss"] = np.array(losses_, dtype=np.float64)
+    for name, v in g.state_dict().items():
+        if full:
+            out["after:" + name] = v.numpy().copy()
+        else:
+            for kk, vv in _summ(v.float()).items():
+                out[f"after_{kk}:" + name] = vv
+    print(f"  loss {losses_}")
+    np.savez_compressed(os.path.join(GOLD, fname), **out)
+
+
 def disc_case(fname, patch, batch, wseed=0, xseed=5):
     print(fname)
     np_sd = W.discriminator_weights(seed=wseed, patch_size=patch)
@@ -164,5 +228,7 @@ if __name__ == "__main__":
     gen_train_case("gen_train_b2_4x3x8x8.npz", 2, (4, 3, 8, 8))
     disc_case("disc_p32_b3.npz", 32, 3)
     loss_case("losses.npz")
+    pretrain_step_case("pretrain_step_f16_b2_4x3x8x8.npz", 16, 2, (4, 3, 8, 8), full=True)
+    pretrain_step_case("pretrain_step_f64_b1_2x3x8x8.npz", 64, 1, (2, 3, 8, 8), full=False)
     # restore the process-wide shared PReLU to its default for anyone importing after us
     print("done ->", GOLD)
