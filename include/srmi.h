@@ -240,6 +240,10 @@ int srmi_mse_loss_bwd(const float* a, const float* b, const float* gout, size_t 
                       void* stream);
 int srmi_bce_loss_bwd(const float* p, const float* t, const float* gout, size_t n, float* dp, void* stream);
 
+/* Gradient of srmi_tv_loss w.r.t. x (NCHW f32), scaled by the upstream scalar gradient gout[0]. */
+int srmi_tv_loss_bwd(const float* x, const float* gout, int32_t N, int32_t C, int32_t H, int32_t W, float weight,
+                     float* dx, void* stream);
+
 /* One Adam update of a flat f32 parameter buffer (torch.optim.Adam defaults; P/mode.py:90, :138-139);
  * `step` is the 1-based step count used for the bias corrections. */
 int srmi_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,

@@ -41,9 +41,13 @@ os.makedirs(GOLD, exist_ok=True)
 torch.set_num_threads(8)
 
 
+QUIET = False
+
+
 def _check(name, a, b, tol=2e-6):
     d = (a - b).abs().max().item()
-    print(f"  oracle-vs-reference {name:28s} max|d| = {d:.3e}")
+    if not QUIET:
+        print(f"  oracle-vs-reference {name:28s} max|d| = {d:.3e}")
     assert d <= tol, (name, d)
 
 
@@ -179,6 +183,157 @@ def pretrain_step_case(fname, n_feats, num_block, shape, full, wseed=0, xseed=21
     np.savez_compressed(os.path.join(GOLD, fname), **out)
 
 
+class VggShaped(torch.nn.Module):
+    """VGG19-shaped frozen stack with recipe weights standing in for torchvision's pretrained net (absent
+    offline).  Built from plain torch.nn layers in torchvision's `features` order; forward returns the 37-entry
+    namedtuple of P/vgg19.py:23-78 (in-place ReLUs, so conv entries alias the relu entries as in the reference)."""
+
+    def __init__(self, np_sd):
+        super().__init__()
+        from collections import namedtuple
+        layers, cin = [], 3
+        for v in W.VGG19_CFG_E:
+            if v == "M":
+                layers.append(torch.nn.MaxPool2d(2, 2))
+            else:
+                layers += [torch.nn.Conv2d(cin, v, 3, padding=1), torch.nn.ReLU(inplace=True)]
+                cin = v
+        self.vgg_feature = torch.nn.Sequential(*layers)
+        self.load_state_dict(O.to_torch(np_sd))
+        for p_ in self.parameters():
+            p_.requires_grad = False
+        self._out = namedtuple("vgg_output", O.VGG_LAYERS)
+
+    def forward(self, x):
+        outs = []
+        for m in self.vgg_feature:
+            x = m(x)
+            outs.append(x)
+        return self._out(*outs)
+
+
+def _put(out, prefix, name, t):
+    t = t.detach().float()
+    n = t.numel()
+    if n <= 4096:
+        out[f"{prefix}:{name}"] = t.numpy().copy()
+        return
+    stride = max(1, n // 2048) | 1
+    flat = t.reshape(-1)
+    out[f"{prefix}_stride:{name}"] = stride
+    out[f"{prefix}_sample:{name}"] = flat[::stride].clone().numpy()
+    out[f"{prefix}_sum:{name}"] = flat.double().sum().item()
+    out[f"{prefix}_sumsq:{name}"] = (flat.double() ** 2).sum().item()
+    out[f"{prefix}_absmax:{name}"] = flat.abs().max().item()
+
+
+def srgan_step_case(fname, num_block, batch, lr_hw, tv_coeff, wseed=0, xseed=31):
+    """One fine-tune iteration, P/mode.py:148-179, run with the REFERENCE Generator, Discriminator,
+    perceptual_loss, TVLoss (imported) and a VGG-shaped recipe-weight stack; mode.py itself cannot be imported
+    (skimage / lpips / DISTS absent), so its loop body is restated line by line below."""
+    import torch.nn as nn
+    import torch.optim as optim
+    print(fname)
+    T_ = __import__("oracle.train_oracle", fromlist=["x"])
+    patch = lr_hw * 4
+    g_np = W.generator_weights(seed=wseed, num_block=num_block)
+    d_np = W.discriminator_weights(seed=wseed + 1, patch_size=patch)
+    v_np = W.vgg19_weights(seed=wseed + 2)
+    generator = Generator(num_block=num_block)
+    generator.load_state_dict(O.to_torch(g_np), strict=True)
+    generator.train()
+    discriminator = Discriminator(patch_size=patch)
+    discriminator.load_state_dict(O.to_torch(d_np), strict=True)
+    discriminator.train()
+    vgg_net = VggShaped(v_np).eval()
+    lr = torch.from_numpy(W.lr_input((batch, 3, lr_hw, lr_hw), seed=xseed))
+    gt = torch.from_numpy(W.lr_input((batch, 3, patch, patch), seed=xseed + 1))
+    vgg_rescale_coeff, adv_coeff, feat_layer = 0.006, 1e-3, "relu5_4"       # P/main.py:16,18,19 defaults
+
+    l2_loss = nn.MSELoss()
+    g_optim = optim.Adam(generator.parameters(), lr=1e-4)
+    d_optim = optim.Adam(discriminator.parameters(), lr=1e-4)
+    VGG_loss = ref_losses.perceptual_loss(vgg_net)
+    cross_ent = nn.BCELoss()
+    tv_loss = ref_losses.TVLoss()
+    real_label = torch.ones((batch, 1))
+    fake_label = torch.zeros((batch, 1))
+
+    # oracle twin
+    gsd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+           for k, v in O.to_torch(g_np).items()}
+    shared = gsd["conv01.body.1.weight"]
+    for k in gsd:
+        if k.endswith(".weight") and gsd[k].shape == (1,):
+            gsd[k] = shared
+    dsd = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+           for k, v in O.to_torch(d_np).items()}
+    vsd = O.to_torch(v_np)
+    gstats, dstats = {}, {}
+    d_part, g_part = T_.srgan_losses(gsd, dsd, vsd, lr, gt, num_block, gstats, dstats, vgg_rescale_coeff, adv_coeff,
+                                     tv_coeff, feat_layer)
+
+    out = dict(num_block=num_block, batch=batch, lr_hw=lr_hw, tv_coeff=tv_coeff, wseed=wseed, xseed=xseed)
+    # ---- Training Discriminator (P/mode.py:148-161)
+    output, _ = generator(lr)
+    fake_prob = discriminator(output)
+    real_prob = discriminator(gt)
+    d_loss_real = cross_ent(real_prob, real_label)
+    d_loss_fake = cross_ent(fake_prob, fake_label)
+    d_loss = d_loss_real + d_loss_fake
+    g_optim.zero_grad()
+    d_optim.zero_grad()
+    d_loss.backward()
+    od_loss = d_part()
+    od_loss.backward()
+    _check("d_loss", d_loss.detach(), od_loss.detach(), tol=1e-6)
+    for name, p_ in discriminator.named_parameters():
+        _check("dgrad " + name[-24:], p_.grad, dsd[name].grad, tol=1e-5 * max(1.0, p_.grad.abs().max().item()))
+        _put(out, "dgrad", name, p_.grad)
+    d_optim.step()
+    with torch.no_grad():                                   # move the oracle's D to the updated parameters
+        for name, p_ in discriminator.named_parameters():
+            dsd[name].copy_(p_)
+            dsd[name].grad = None
+    for k in gsd.values():
+        if k.grad is not None:
+            k.grad = None
+    # ---- Training Generator (P/mode.py:163-179)
+    output, _ = generator(lr)
+    fake_prob = discriminator(output)
+    _percep_loss, hr_feat, sr_feat = VGG_loss((gt + 1.0) / 2.0, (output + 1.0) / 2.0, layer=feat_layer)
+    L2_loss = l2_loss(output, gt)
+    percep_loss = vgg_rescale_coeff * _percep_loss
+    adversarial_loss = adv_coeff * cross_ent(fake_prob, real_label)
+    total_variance_loss = tv_coeff * tv_loss(vgg_rescale_coeff * (hr_feat - sr_feat) ** 2)
+    g_loss = percep_loss + adversarial_loss + total_variance_loss + L2_loss
+    g_optim.zero_grad()
+    d_optim.zero_grad()
+    g_loss.backward()
+    og_loss, parts = g_part()
+    og_loss.backward()
+    _check("g_loss", g_loss.detach(), og_loss.detach(), tol=2e-6 * max(1.0, abs(g_loss.item())))
+    _check("percep", percep_loss.detach(), parts["percep"].detach(), tol=2e-6 * max(1.0, abs(percep_loss.item())))
+    for name, p_ in generator.named_parameters():
+        _check("ggrad " + name[-24:], p_.grad, gsd[name].grad, tol=2e-5 * max(1.0, p_.grad.abs().max().item()))
+        _put(out, "ggrad", name, p_.grad)
+    g_optim.step()
+    out.update(d_loss=d_loss.item(), g_loss=g_loss.item(), percep_loss=percep_loss.item(),
+               adversarial_loss=adversarial_loss.item(), total_variance_loss=total_variance_loss.item(),
+               L2_loss=L2_loss.item(), hr_feat_absmax=hr_feat.abs().max().item())
+    for name, v in generator.state_dict().items():
+        _put(out, "after_g", name, v)
+    for name, v in discriminator.state_dict().items():
+        _put(out, "after_d", name, v)
+    for k in gstats:
+        _check("G " + k[-28:], generator.state_dict()[k].double(), gstats[k].double(), tol=1e-5)
+    for k in dstats:
+        _check("D " + k[-28:], discriminator.state_dict()[k].double(), dstats[k].double(), tol=1e-5)
+    print(f"  d_loss {d_loss.item():.6f} g_loss {g_loss.item():.6f} percep {percep_loss.item():.6f} "
+          f"adv {adversarial_loss.item():.6f} tv {total_variance_loss.item():.3e} L2 {L2_loss.item():.6f}")
+    np.savez_compressed(os.path.join(GOLD, fname), **out)
+
+
 def disc_case(fname, patch, batch, wseed=0, xseed=5):
     print(fname)
     np_sd = W.discriminator_weights(seed=wseed, patch_size=patch)
@@ -230,5 +385,10 @@ if __name__ == "__main__":
     loss_case("losses.npz")
     pretrain_step_case("pretrain_step_f16_b2_4x3x8x8.npz", 16, 2, (4, 3, 8, 8), full=True)
     pretrain_step_case("pretrain_step_f64_b1_2x3x8x8.npz", 64, 1, (2, 3, 8, 8), full=False)
+    # batch 8 x LR 16 (HR 64): the smallest size at which the discriminator's deepest train-mode BatchNorm
+    # (N*4*4 = 128 elements per channel) is well conditioned - at batch 2 x LR 8 the REFERENCE's own fp32
+    # gradients sit 0.5-3 % away from an fp64 run of the same graph, so nothing can be pinned to them.
+    srgan_step_case("srgan_step_b8_lr16_tv0.npz", 2, 8, 16, 0.0)            # reference defaults (tv coeff 0, P/main.py:17)
+    srgan_step_case("srgan_step_b8_lr16_tv.npz", 2, 8, 16, 2e-2, xseed=41)  # TV term switched on
     # restore the process-wide shared PReLU to its default for anyone importing after us
     print("done ->", GOLD)

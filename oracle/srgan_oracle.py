@@ -134,6 +134,42 @@ def mean_shift(x, mean=(0.485, 0.456, 0.406), std=(0.229, 0.224, 0.225)):
     return x / s - m / s
 
 
+VGG_LAYERS = ['conv1_1', 'relu1_1', 'conv1_2', 'relu1_2', 'pool1',
+              'conv2_1', 'relu2_1', 'conv2_2', 'relu2_2', 'pool2',
+              'conv3_1', 'relu3_1', 'conv3_2', 'relu3_2', 'conv3_3', 'relu3_3', 'conv3_4', 'relu3_4', 'pool3',
+              'conv4_1', 'relu4_1', 'conv4_2', 'relu4_2', 'conv4_3', 'relu4_3', 'conv4_4', 'relu4_4', 'pool4',
+              'conv5_1', 'relu5_1', 'conv5_2', 'relu5_2', 'conv5_3', 'relu5_3', 'conv5_4', 'relu5_4', 'pool5']
+
+
+def vgg19_features(sd, x, upto="relu5_4"):
+    """`vgg19.forward` (P/vgg19.py:23-78) over torchvision's VGG19-E `features` (conv3x3 pad 1, ReLU, 2x2
+    max-pool).  torchvision's ReLUs are in-place, so each `convX_Y` entry the reference returns aliases the
+    post-ReLU tensor; the dict returned here maps both names to the post-ReLU value.  Stops after `upto`."""
+    out = {}
+    idx = 0
+    names = iter(VGG_LAYERS)
+    for v in [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]:
+        if v == "M":
+            x = F.max_pool2d(x, 2, 2)
+            out[next(names)] = x
+            idx += 1
+        else:
+            x = F.relu(F.conv2d(x, sd[f"vgg_feature.{idx}.weight"], sd[f"vgg_feature.{idx}.bias"], padding=1))
+            out[next(names)] = x
+            out[next(names)] = x
+            idx += 2
+        if upto in out:
+            break
+    return out
+
+
+def perceptual_loss(vgg_sd, HR, SR, layer="relu5_4"):
+    """`perceptual_loss.forward` (P/losses.py:29-39) -> (mse, hr_feat, sr_feat); HR, SR in [0,1]."""
+    hr_feat = vgg19_features(vgg_sd, mean_shift(HR), layer)[layer]
+    sr_feat = vgg19_features(vgg_sd, mean_shift(SR), layer)[layer]
+    return F.mse_loss(hr_feat, sr_feat), hr_feat, sr_feat
+
+
 def to_torch(np_sd, dtype=torch.float32):
     """numpy recipe dict -> torch dict (floating entries cast to ``dtype``)."""
     out = {}

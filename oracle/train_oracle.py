@@ -52,3 +52,33 @@ def adam_step(params, grads, state, lr=1e-4, betas=(0.9, 0.999), eps=1e-8):
         state["v"][i] = state["v"][i] * b2 + (1 - b2) * g * g
         denom = state["v"][i].sqrt() / (1 - b2 ** t) ** 0.5 + eps
         p -= (lr / (1 - b1 ** t)) * state["m"][i] / denom
+
+
+def srgan_losses(gsd, dsd, vsd, lr, gt, num_block, gstats, dstats, vgg_rescale_coeff=0.006, adv_coeff=1e-3,
+                 tv_loss_coeff=0.0, feat_layer="relu5_4"):
+    """The loss arithmetic of one fine-tune iteration (P/mode.py:148-174) as two closures over parameter
+    dicts, so that the caller can interleave the optimizer steps exactly as the reference does:
+        d_loss = d_part()      # :149-156, G fwd #1, D(fake), D(real)
+        g_loss = g_part()      # :164-174, G fwd #2, D(fake) with the UPDATED D, VGG, L2, TV
+    BN running statistics are threaded through gstats / dstats (train-mode BN, every forward updates them)."""
+    from oracle import srgan_oracle as O
+
+    def d_part():
+        output, _ = O.generator_forward(gsd, lr, num_block=num_block, training=True, stats_out=gstats)
+        fake_prob = O.discriminator_forward(dsd, output, training=True, stats_out=dstats)
+        real_prob = O.discriminator_forward(dsd, gt, training=True, stats_out=dstats)
+        d_loss_real = F.binary_cross_entropy(real_prob, torch.ones_like(real_prob))
+        d_loss_fake = F.binary_cross_entropy(fake_prob, torch.zeros_like(fake_prob))
+        return d_loss_real + d_loss_fake
+
+    def g_part():
+        output, _ = O.generator_forward(gsd, lr, num_block=num_block, training=True, stats_out=gstats)
+        fake_prob = O.discriminator_forward(dsd, output, training=True, stats_out=dstats)
+        _percep, hr_feat, sr_feat = O.perceptual_loss(vsd, (gt + 1.0) / 2.0, (output + 1.0) / 2.0, feat_layer)
+        L2 = F.mse_loss(output, gt)
+        percep = vgg_rescale_coeff * _percep
+        adv = adv_coeff * F.binary_cross_entropy(fake_prob, torch.ones_like(fake_prob))
+        tv = tv_loss_coeff * O.tv_loss(vgg_rescale_coeff * (hr_feat - sr_feat) ** 2)
+        return percep + adv + tv + L2, dict(percep=percep, adv=adv, tv=tv, l2=L2)
+
+    return d_part, g_part

@@ -83,6 +83,30 @@ def discriminator_schema(img_feat=3, n_feats=64, num_of_block=3, patch_size=96):
     return s
 
 
+VGG19_CFG_E = [64, 64, "M", 128, 128, "M", 256, 256, 256, 256, "M", 512, 512, 512, 512, "M", 512, 512, 512, 512, "M"]
+
+
+def vgg19_schema():
+    """Ordered key -> (shape, kind) of torchvision's vgg19 `features` stack as wrapped by P/vgg19.py:11
+    (`vgg_feature.<index>.weight/bias`; public VGG19 "E" configuration, conv3x3 pad 1 + ReLU, 2x2 max-pools)."""
+    s = OrderedDict()
+    idx, cin = 0, 3
+    for v in VGG19_CFG_E:
+        if v == "M":
+            idx += 1
+        else:
+            _conv(s, f"vgg_feature.{idx}", v, cin, 3)
+            cin = v
+            idx += 2
+    return s
+
+
+def vgg19_weights(seed=0):
+    """Seeded stand-in for the ImageNet weights (unavailable offline): He-scaled so that activations and
+    gradients survive the 16 ReLU layers."""
+    return fill(vgg19_schema(), seed=seed, gain=1.4142)
+
+
 def _rng(seed, key):
     return np.random.Generator(np.random.PCG64([int(seed), zlib.crc32(key.encode())]))
 

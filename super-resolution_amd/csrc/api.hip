@@ -41,6 +41,7 @@ int mse_bwd(const float* a, const float* b, const float* gout, size_t n, float* 
 int bce_bwd(const float* p, const float* t, const float* gout, size_t n, float* dp, hipStream_t s);
 int adam_step(float* param, const float* grad, float* m, float* v, size_t n, float lr, float beta1, float beta2,
               float eps, int step, hipStream_t s);
+int tv_bwd(const float* x, const float* gout, int N, int C, int H, int W, float weight, float* dx, hipStream_t s);
 size_t generic_dgrad_packed_bytes(const srmi_conv_desc& d);
 int generic_dgrad_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s);
 int generic_dgrad_launch(const srmi_conv_desc& d, const ConvGeom& g, const float* dz, const float* w_dgrad, float* dx,
@@ -419,6 +420,13 @@ int srmi_mse_loss_bwd(const float* a, const float* b, const float* gout, size_t 
 int srmi_bce_loss_bwd(const float* p, const float* t, const float* gout, size_t n, float* dp, void* stream) {
     if (!p || !t || !gout || !dp) { set_error("bce_loss_bwd: NULL argument"); return SRMI_EINVAL; }
     return bce_bwd(p, t, gout, n, dp, (hipStream_t)stream);
+}
+
+int srmi_tv_loss_bwd(const float* x, const float* gout, int32_t N, int32_t C, int32_t H, int32_t W, float weight,
+                     float* dx, void* stream) {
+    if (!x || !gout || !dx) { set_error("tv_loss_bwd: NULL argument"); return SRMI_EINVAL; }
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) { set_error("tv_loss_bwd: bad dims"); return SRMI_EINVAL; }
+    return tv_bwd(x, gout, N, C, H, W, weight, dx, (hipStream_t)stream);
 }
 
 int srmi_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,

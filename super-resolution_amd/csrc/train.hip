@@ -237,6 +237,25 @@ __global__ __launch_bounds__(CH_BLOCK) void bce_bwd_kernel(const float* __restri
     }
 }
 
+// d TVLoss / dx (P/losses.py:46-55): every element takes part in up to two vertical and two horizontal
+// squared differences.  kh = weight*2/(count_h*N) * 2, kw likewise; gout = upstream scalar gradient.
+__global__ __launch_bounds__(CH_BLOCK) void tv_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gout,
+                                                          size_t total, int H, int W, float kh, float kw,
+                                                          float* __restrict__ dx) {
+    const float g = gout[0];
+    for (size_t i = (size_t)blockIdx.x * CH_BLOCK + threadIdx.x; i < total; i += (size_t)gridDim.x * CH_BLOCK) {
+        const int xc = (int)(i % W);
+        const int yr = (int)((i / W) % H);
+        const float v = x[i];
+        float a = 0.f, b = 0.f;
+        if (yr > 0) a += v - x[i - W];
+        if (yr < H - 1) a -= x[i + W] - v;
+        if (xc > 0) b += v - x[i - 1];
+        if (xc < W - 1) b -= x[i + 1] - v;
+        dx[i] = g * (kh * a + kw * b);
+    }
+}
+
 // ---- Adam (torch.optim.Adam defaults: no amsgrad, weight_decay 0; P/mode.py:90, :138-139) -------------
 __global__ __launch_bounds__(CH_BLOCK) void adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
                                                         float* __restrict__ m, float* __restrict__ v, size_t n,
@@ -348,6 +367,16 @@ int bce_bwd(const float* p, const float* t, const float* gout, size_t n, float* 
     if (n == 0) return SRMI_OK;
     hipLaunchKernelGGL(bce_bwd_kernel, dim3(ew_blocks(n)), dim3(CH_BLOCK), 0, s, p, t, gout, n, dp);
     return hip_check(hipGetLastError(), "bce_bwd_kernel");
+}
+
+int tv_bwd(const float* x, const float* gout, int N, int C, int H, int W, float weight, float* dx, hipStream_t s) {
+    const size_t total = (size_t)N * C * H * W;
+    if (total == 0) return SRMI_OK;
+    const double count_h = (double)C * (H - 1) * W, count_w = (double)C * H * (W - 1);
+    const double k = 2.0 * (double)weight / (double)N * 2.0;
+    hipLaunchKernelGGL(tv_bwd_kernel, dim3(ew_blocks(total)), dim3(CH_BLOCK), 0, s, x, gout, total, H, W,
+                       (float)(k / count_h), (float)(k / count_w), dx);
+    return hip_check(hipGetLastError(), "tv_bwd_kernel");
 }
 
 int adam_step(float* param, const float* grad, float* m, float* v, size_t n, float lr, float beta1, float beta2,

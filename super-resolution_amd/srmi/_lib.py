@@ -100,6 +100,8 @@ SYMBOLS = {
                                       C.c_void_p]),
     "srmi_mse_loss_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "srmi_bce_loss_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
+    "srmi_tv_loss_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                   C.c_void_p, C.c_void_p]),
     "srmi_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float,
                                  C.c_float, C.c_float, C.c_int32, C.c_void_p]),
 }

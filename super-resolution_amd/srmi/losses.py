@@ -112,8 +112,30 @@ class BCELoss(nn.Module):
         return bce_loss(p, t)
 
 
+class _TVFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        x = _f32c(x, "input")           # the kernels index x as dense NCHW
+        N, C_, H, W = x.shape
+        out = torch.empty((), dtype=torch.float32, device=x.device)
+        L.check(L.load().srmi_tv_loss(x.data_ptr(), N, C_, H, W, weight, out.data_ptr(),
+                                      _workspace(x.device).data_ptr(), stream_ptr()))
+        ctx.save_for_backward(x)
+        ctx.weight = weight
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        N, C_, H, W = x.shape
+        dx = torch.empty_like(x)
+        L.check(L.load().srmi_tv_loss_bwd(x.data_ptr(), g.contiguous().data_ptr(), N, C_, H, W, ctx.weight,
+                                          dx.data_ptr(), stream_ptr()))
+        return dx, None
+
+
 class TVLoss(nn.Module):
-    """Same constructor and call as the reference's ``TVLoss`` (P/losses.py:41-59)."""
+    """Same constructor and call as the reference's ``TVLoss`` (P/losses.py:41-59); differentiable."""
 
     def __init__(self, tv_loss_weight=1):
         super().__init__()
@@ -122,13 +144,48 @@ class TVLoss(nn.Module):
     def forward(self, x):
         if x.dim() != 4:
             raise ValueError("TVLoss expects an NCHW tensor")
-        x = _f32c(x, "input")
-        N, C_, H, W = x.shape
-        out = torch.empty((), dtype=torch.float32, device=x.device)
-        L.check(L.load().srmi_tv_loss(x.data_ptr(), N, C_, H, W, float(self.tv_loss_weight), out.data_ptr(),
-                                      _workspace(x.device).data_ptr(), stream_ptr()))
-        return out
+        return _TVFn.apply(x, float(self.tv_loss_weight))
 
     @staticmethod
     def tensor_size(t):
         return t.size()[1] * t.size()[2] * t.size()[3]
+
+
+class MeanShift(nn.Conv2d):
+    """`MeanShift` (P/losses.py:6-19): frozen 1x1 conv, weight eye/std, bias sign*rgb_range*mean/std."""
+
+    def __init__(self, rgb_range=1, norm_mean=(0.485, 0.456, 0.406), norm_std=(0.229, 0.224, 0.225), sign=-1):
+        super().__init__(3, 3, kernel_size=1)
+        std = torch.Tensor(norm_std)
+        self.weight.data = torch.eye(3).view(3, 3, 1, 1) / std.view(3, 1, 1, 1)
+        self.bias.data = sign * rgb_range * torch.Tensor(norm_mean) / std
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def forward(self, x):
+        from .autograd import fused_conv
+        require_cuda(x)
+        return fused_conv(x, self, None, None)
+
+
+class perceptual_loss(nn.Module):
+    """`perceptual_loss` (P/losses.py:21-39): MeanShift -> vgg -> MSE at `layer`; returns
+    (loss, hr_feat, sr_feat).  HR and SR are expected in [0,1]."""
+
+    def __init__(self, vgg):
+        super().__init__()
+        self.normalization_mean = [0.485, 0.456, 0.406]
+        self.normalization_std = [0.229, 0.224, 0.225]
+        self.transform = MeanShift(norm_mean=self.normalization_mean, norm_std=self.normalization_std)
+        self.vgg = vgg
+        self.criterion = MSELoss()
+
+    def forward(self, HR, SR, layer="relu5_4"):
+        dev = HR.device
+        if self.transform.weight.device != dev:
+            self.transform.to(dev)
+        hr = self.transform(HR)
+        sr = self.transform(SR)
+        hr_feat = getattr(self.vgg(hr), layer)
+        sr_feat = getattr(self.vgg(sr), layer)
+        return self.criterion(hr_feat, sr_feat), hr_feat, sr_feat

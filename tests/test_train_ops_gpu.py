@@ -43,6 +43,9 @@ CASES = [
     (2, 8, 8, 64, 128, 3, 1, False, "relu", 1, False, False, False),    # VGG conv + ReLU
     (4, 1, 1, 40, 1, 1, 1, False, "sigmoid", 1, False, False, False),   # Linear + Sigmoid
     (2, 7, 7, 5, 20, 5, 1, True, "relu", 1, False, True, False),        # odd channels, 5x5
+    (8, 8, 8, 512, 512, 3, 2, True, "lrelu", 1, False, False, False),   # D body.2.body.1 at patch 64
+    (8, 8, 8, 256, 512, 3, 1, True, "lrelu", 1, False, False, False),   # D body.2.body.0 at patch 64
+    (4, 4, 4, 512, 1024, 4, 1, False, "lrelu", 1, False, False, False), # wide layer, even kernel
 ]
 
 
