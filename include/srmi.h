@@ -94,8 +94,8 @@ typedef struct srmi_conv_args {
     srmi_conv_desc d;
     const void* x;         /* input activations */
     const void* w;         /* weights packed by srmi_conv2d_pack_weights for THIS descriptor */
-    const float* scale;    /* [Cout] f32 */
-    const float* shift;    /* [Cout] f32 */
+    const float* scale;    /* [Cout] f32; NULL = all ones (SRMI_COMPUTE_F32 generic kernel only) */
+    const float* shift;    /* [Cout] f32; NULL = all zeros (same restriction) */
     const float* alpha;    /* PReLU slope(s), f32, device memory (read in-kernel: no host sync) */
     const void* residual;  /* NULL or a dense tensor shaped like the final output */
     void* y;               /* output */

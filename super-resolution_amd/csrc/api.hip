@@ -125,8 +125,12 @@ static int conv_fwd_one(const srmi_conv_args* a, hipStream_t s) {
     int rc = conv_geom(a->d, &g);
     if (rc) return rc;
     if ((long long)a->d.N * g.Ho * g.Wo == 0) return SRMI_OK;  // empty batch / image: nothing to do
-    if (!a->x || !a->w || !a->scale || !a->shift || !a->y) {
-        set_error("conv: NULL x/w/scale/shift/y");
+    if (!a->x || !a->w || !a->y) {
+        set_error("conv: NULL x/w/y");
+        return SRMI_EINVAL;
+    }
+    if ((!a->scale || !a->shift) && select_kernel(a->d) != K_GENERIC_F32) {
+        set_error("conv: NULL scale/shift (= 1 / 0) is only accepted by the generic f32 kernel");
         return SRMI_EINVAL;
     }
     if (a->d.act == SRMI_ACT_PRELU && !a->alpha) {

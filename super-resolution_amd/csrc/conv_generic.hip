@@ -25,6 +25,7 @@ struct GenericParams {
     int act; float act_param; int alpha_pc; int r; int dcr;
     int Cin_pad, Cout_pad, M;
     hipStream_t stream;
+    int ksplit;      // > 1: grid.z slices of K, partial sums added to a pre-zeroed f32 y (no activation / residual)
     int transposed;  // dgrad: gather dz at (o + pad - k) / stride where divisible
 };
 
@@ -54,58 +55,63 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(GenericParams p) {
     const bf16_t* xb = (const bf16_t*)p.x;
     const size_t HW = (size_t)p.H * p.W;
 
-    for (int ky = 0; ky < p.kh; ++ky) {
-        int iy = oy * p.stride - p.pad + ky;
-        bool vy = true;
+    // K space = (tap, 8-channel chunk); a split-K launch (blockIdx.z) walks only its slice of it
+    const int cpt = p.Cin_pad >> 3;                 // chunks per tap
+    const int KC = p.kh * p.kw * cpt;
+    int kc = 0, kc1 = KC;
+    if (p.ksplit > 1) {
+        const int per = (KC + p.ksplit - 1) / p.ksplit;
+        kc = blockIdx.z * per;
+        kc1 = min(KC, kc + per);
+    }
+    while (kc < kc1) {
+        const int tap = kc / cpt;
+        const int cbeg = (kc - tap * cpt) << 3;
+        const int cend = min(p.Cin_pad, cbeg + ((kc1 - kc) << 3));
+        kc += (cend - cbeg) >> 3;
+        const int ky = tap / p.kw, kx = tap - ky * p.kw;
+        int iy = oy * p.stride - p.pad + ky, ix = ox * p.stride - p.pad + kx;
+        bool vt = true;
         if (p.transposed) {
-            const int ty = oy + p.pad - ky;
-            vy = ty >= 0 && ty % p.stride == 0;
+            const int ty = oy + p.pad - ky, tx = ox + p.pad - kx;
+            vt = ty >= 0 && tx >= 0 && ty % p.stride == 0 && tx % p.stride == 0;
             iy = ty / p.stride;
+            ix = tx / p.stride;
         }
-        for (int kx = 0; kx < p.kw; ++kx) {
-            int ix = ox * p.stride - p.pad + kx;
-            bool vx = true;
-            if (p.transposed) {
-                const int tx = ox + p.pad - kx;
-                vx = tx >= 0 && tx % p.stride == 0;
-                ix = tx / p.stride;
-            }
-            const bool v = mvalid && vy && vx && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-            const int tap = ky * p.kw + kx;
-            const float* wt = p.w + (size_t)tap * p.Cin_pad * p.Cout_pad + co0 + i;
-            const size_t pix = v ? (((size_t)n * p.H + iy) * p.W + ix) : 0;
-            for (int c0 = 0; c0 < p.Cin_pad; c0 += 8) {
-                const int cb = c0 + 4 * h;
-                float a[4] = {0.f, 0.f, 0.f, 0.f};
-                if (v) {
-                    if (p.vec_ok) {  // NHWC, Cin % 8 == 0, 16-B aligned rows
-                        if (p.in_bf16) {
-                            const u16x4 q = *(const u16x4*)(xb + pix * p.in_cs + cb);
-                            a[0] = bf2f(q[0]); a[1] = bf2f(q[1]); a[2] = bf2f(q[2]); a[3] = bf2f(q[3]);
-                        } else {
-                            const f32x4 q = *(const f32x4*)(xf + pix * p.in_cs + cb);
-                            a[0] = q[0]; a[1] = q[1]; a[2] = q[2]; a[3] = q[3];
-                        }
+        const bool v = mvalid && vt && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+        const float* wt = p.w + (size_t)tap * p.Cin_pad * p.Cout_pad + co0 + i;
+        const size_t pix = v ? (((size_t)n * p.H + iy) * p.W + ix) : 0;
+        for (int c0 = cbeg; c0 < cend; c0 += 8) {
+            const int cb = c0 + 4 * h;
+            float a[4] = {0.f, 0.f, 0.f, 0.f};
+            if (v) {
+                if (p.vec_ok) {  // NHWC, Cin % 8 == 0, 16-B aligned rows
+                    if (p.in_bf16) {
+                        const u16x4 q = *(const u16x4*)(xb + pix * p.in_cs + cb);
+                        a[0] = bf2f(q[0]); a[1] = bf2f(q[1]); a[2] = bf2f(q[2]); a[3] = bf2f(q[3]);
                     } else {
+                        const f32x4 q = *(const f32x4*)(xf + pix * p.in_cs + cb);
+                        a[0] = q[0]; a[1] = q[1]; a[2] = q[2]; a[3] = q[3];
+                    }
+                } else {
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) {
-                            const int c = cb + j;
-                            if (c < p.Cin) {
-                                const size_t idx = p.in_nchw
-                                    ? ((size_t)n * p.Cin + c) * HW + (size_t)iy * p.W + ix
-                                    : pix * p.in_cs + c;
-                                a[j] = p.in_bf16 ? bf2f(xb[idx]) : xf[idx];
-                            }
+                    for (int j = 0; j < 4; ++j) {
+                        const int c = cb + j;
+                        if (c < p.Cin) {
+                            const size_t idx = p.in_nchw
+                                ? ((size_t)n * p.Cin + c) * HW + (size_t)iy * p.W + ix
+                                : pix * p.in_cs + c;
+                            a[j] = p.in_bf16 ? bf2f(xb[idx]) : xf[idx];
                         }
                     }
                 }
+            }
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float* wr = wt + (size_t)(cb + j) * p.Cout_pad;
+            for (int j = 0; j < 4; ++j) {
+                const float* wr = wt + (size_t)(cb + j) * p.Cout_pad;
 #pragma unroll
-                    for (int t = 0; t < NT; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], wr[32 * t], acc[t], 0, 0, 0);
-                }
+                for (int t = 0; t < NT; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], wr[32 * t], acc[t], 0, 0, 0);
             }
         }
     }
@@ -117,7 +123,8 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(GenericParams p) {
         const int co = co0 + 32 * t + i;
         const bool cvalid = co < p.Cout;
         const int coc = cvalid ? co : 0;
-        const float sc = p.scale ? p.scale[coc] : 1.f, sh = p.shift ? p.shift[coc] : 0.f;
+        const float sc = p.scale ? p.scale[coc] : 1.f;
+        const float sh = (p.shift && (p.ksplit <= 1 || blockIdx.z == 0)) ? p.shift[coc] : 0.f;
         const float al = (p.act == SRMI_ACT_PRELU) ? p.alpha[p.alpha_pc ? coc : 0] : 0.f;
         int c = coc, si = 0, sj = 0;
         if (p.r > 1) {
@@ -140,6 +147,7 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(GenericParams p) {
                 oidx = px * p.out_cs + p.out_co + c;
                 ridx = px * p.res_cs + c;
             }
+            if (p.ksplit > 1) { unsafeAtomicAdd((float*)p.y + oidx, val); continue; }
             if (p.res) val += p.res_bf16 ? bf2f(((const bf16_t*)p.res)[ridx]) : ((const float*)p.res)[ridx];
             if (p.out_bf16) ((bf16_t*)p.y)[oidx] = f2bf(val);
             else ((float*)p.y)[oidx] = val;
@@ -236,18 +244,40 @@ int generic_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     if (M > 0x7fffffffLL) { set_error("generic conv: N*Ho*Wo = %lld exceeds int32", M); return SRMI_EINVAL; }
     p.M = (int)M;
     p.transposed = 0;
+    p.ksplit = 1;
     if (p.M == 0) return SRMI_OK;
     return generic_run(p);
 }
 
-static int generic_run(const GenericParams& p) {
+static int generic_run(const GenericParams& p0) {
+    GenericParams p = p0;
     hipStream_t s = p.stream;
     const unsigned gx = (unsigned)((p.M + 127) / 128);
+    const unsigned gy = p.Cout > 32 ? (unsigned)((p.Cout + 63) / 64) : 1u;
+    // Split K when the pixel x channel tiling alone cannot fill 256 CUs (deep, spatially small layers: the
+    // discriminator tail, VGG conv4/conv5, Linear layers, their dgrads).  Needs a linear epilogue with unit
+    // scale and a dense f32 output, which is what the training path asks for; partials meet in f32 atomics.
+    p.ksplit = 1;
+    const long long waves = (long long)((p.M + 31) / 32) * gy;
+    const int KC = p.kh * p.kw * (p.Cin_pad / 8);
+    if (!p.scale && p.act == SRMI_ACT_NONE && !p.res && !p.out_bf16 && p.r == 1 && waves < 2048 && KC >= 16) {
+        long long ks = (4096 + waves - 1) / waves;
+        if (ks > KC / 8) ks = KC / 8;              // at least 8 chunks (64 channels of one tap) per slice
+        if (ks > 256) ks = 256;
+        if (ks > 1) {
+            p.ksplit = (int)ks;
+            const size_t bytes = (size_t)p.N * p.Cf * p.Hf * p.Wf * sizeof(float);
+            if (!p.out_nchw && p.out_cs != p.Cf) { p.ksplit = 1; }   // channel-slice outputs cannot be zero-filled
+            else {
+                int rc = hip_check(hipMemsetAsync(p.y, 0, bytes, s), "split-K memset");
+                if (rc) return rc;
+            }
+        }
+    }
+    dim3 grid(gx, gy, (unsigned)p.ksplit);
     if (p.Cout > 32) {
-        dim3 grid(gx, (unsigned)((p.Cout + 63) / 64));
         hipLaunchKernelGGL(conv_generic_kernel<2>, grid, dim3(256), 0, s, p);
     } else {
-        dim3 grid(gx, 1);
         hipLaunchKernelGGL(conv_generic_kernel<1>, grid, dim3(256), 0, s, p);
     }
     return hip_check(hipGetLastError(), "conv_generic_kernel");

@@ -105,8 +105,8 @@ def fill_args(a: L.ConvArgs, desc, x, w, scale, shift, alpha, residual, y):
     a.d = desc
     a.x = x.data_ptr() if isinstance(x, torch.Tensor) else x
     a.w = w.data_ptr()
-    a.scale = scale.data_ptr()
-    a.shift = shift.data_ptr()
+    a.scale = scale.data_ptr() if scale is not None else None
+    a.shift = shift.data_ptr() if shift is not None else None
     a.alpha = alpha.data_ptr() if alpha is not None else None
     a.residual = residual.data_ptr() if residual is not None else None
     a.y = y.data_ptr()

@@ -195,11 +195,15 @@ def test_guards():
     gen = Generator(num_block=1).to(DEV)
     x = torch.zeros(1, 3, 8, 8, device=DEV)
     gen.train()
-    with torch.no_grad(), pytest.raises(NotImplementedError, match="BatchNorm"):
-        gen(x)
+    with torch.no_grad():                      # train-mode BN runs on the training kernels (tests/test_train_step_gpu.py)
+        sr, _ = gen(x)
+    assert sr.shape == (1, 3, 32, 32)
     gen.eval()
-    with pytest.raises(NotImplementedError, match="autograd"):
-        gen(x)
+    with pytest.raises(NotImplementedError, match="eval-mode BatchNorm"):
+        gen(x)                                 # autograd recording through eval-mode BN: not a path of the reference loops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        gen.cpu()(x.cpu())
+    gen.to(DEV)
 
 
 def test_discriminator_eval_matches_reference(golden_dir):

@@ -1,0 +1,89 @@
+"""CPU, world_size 2 over gloo: the one exchange step of data-parallel training - bucketed
+gradient averaging equals the mean of the per-rank gradients, and two ranks that each see half of a batch
+and average their gradients take the same Adam step as one process that averages the two half-batch
+gradients itself (the N-rank oracle of SURVEY 8e2)."""
+import os
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn as nn
+
+from srmi import parallel
+
+
+def _model():
+    torch.manual_seed(0)
+    return nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.PReLU(), nn.Conv2d(8, 3, 3, padding=1))
+
+
+def _data():
+    g = torch.Generator().manual_seed(1)
+    return torch.randn(4, 3, 6, 6, generator=g), torch.randn(4, 3, 6, 6, generator=g)
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        m = _model()
+        if rank == 1:                                # start from different parameters: broadcast must fix it
+            with torch.no_grad():
+                for p in m.parameters():
+                    p.add_(1.0)
+        parallel.broadcast_parameters(m, src=0)
+        x, y = _data()
+        xs, ys = x[rank * 2:(rank + 1) * 2], y[rank * 2:(rank + 1) * 2]
+        opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+        loss = nn.functional.mse_loss(m(xs), ys)
+        opt.zero_grad()
+        loss.backward()
+        local = [p.grad.clone() for p in m.parameters()]
+        nb = parallel.average_gradients(m.parameters(), max_buckets=2)
+        opt.step()
+        q.put((rank, nb, [t.numpy() for t in local], [p.grad.numpy().copy() for p in m.parameters()],
+               [p.detach().numpy().copy() for p in m.parameters()]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gradient_average_matches_single_process_oracle():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == res[1][1] >= 1
+    # averaged gradient == mean of the local gradients, identical on both ranks
+    for l0, l1, a0, a1 in zip(res[0][2], res[1][2], res[0][3], res[1][3]):
+        assert abs((l0 + l1) / 2 - a0).max() <= 1e-7
+        assert (a0 == a1).all()
+    # single-process oracle: two micro-batches, separate forwards, gradients averaged, one Adam step
+    m = _model()
+    x, y = _data()
+    grads = []
+    for r in range(2):
+        m.zero_grad()
+        nn.functional.mse_loss(m(x[r * 2:(r + 1) * 2]), y[r * 2:(r + 1) * 2]).backward()
+        grads.append([p.grad.clone() for p in m.parameters()])
+    opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+    for p, g0, g1 in zip(m.parameters(), *grads):
+        p.grad = (g0 + g1) / 2
+    opt.step()
+    for p, q0, q1 in zip(m.parameters(), res[0][4], res[1][4]):
+        assert abs(p.detach().numpy() - q0).max() <= 1e-6
+        assert (q0 == q1).all()
+
+
+def test_average_is_noop_without_process_group():
+    m = _model()
+    nn.functional.mse_loss(m(_data()[0]), _data()[1]).backward()
+    before = [p.grad.clone() for p in m.parameters()]
+    assert parallel.average_gradients(m.parameters()) == 0
+    assert all(torch.equal(a, p.grad) for a, p in zip(before, m.parameters()))

@@ -1,0 +1,127 @@
+#!/usr/bin/env python3
+"""Secondary benchmark (BASELINE config 3 / SURVEY 8d2 cfg3): one SRGAN fine-tune iteration, P/mode.py:148-179,
+per GPU LR 16x3x24x24 -> HR 16x3x96x96, Discriminator(patch_size=96), VGG19-shaped frozen stack (seeded weights),
+Adam for G and D, fp32 training kernels.  With torch.distributed.run and N ranks the two gradient exchanges of
+SURVEY 8e2 run over RCCL (srmi.parallel.average_gradients).
+
+    python tools/bench_train_step.py [--steps K] [--warmup W]
+
+Prints one JSON line: steps/s (whole job), ms per step, HR megapixels/s.  Not the headline metric (bench.py is).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "super-resolution_amd")]
+
+import torch
+import torch.optim as optim
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--lr-size", type=int, default=24)
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+
+    from bench import synthetic_state
+    from srmi import losses, parallel
+    from srmi.srgan_model import Discriminator, Generator
+    from srmi.vgg19 import vgg19
+
+    B, L = args.batch, args.lr_size
+    generator = Generator()
+    generator.load_state_dict(synthetic_state(generator, 0))
+    generator = generator.to(dev).train()
+    discriminator = Discriminator(patch_size=L * 4)
+    dsd = synthetic_state(discriminator, 1)
+    for k, v in discriminator.state_dict().items():          # Linear layers: keep torch's init scale
+        if v.dim() == 2:
+            dsd[k] = torch.randn(v.shape, generator=torch.Generator().manual_seed(2)) / v.shape[1] ** 0.5
+    discriminator.load_state_dict(dsd)
+    discriminator = discriminator.to(dev).train()
+    vgg_net = vgg19(pre_trained=False)
+    vsd = {k: (torch.randn(v.shape, generator=torch.Generator().manual_seed(3)) * (2.0 / (v.shape[1] * 9)) ** 0.5
+               if v.dim() == 4 else torch.zeros(v.shape)) for k, v in vgg_net.state_dict().items()}
+    vgg_net.load_state_dict(vsd)
+    vgg_net = vgg_net.to(dev).eval()
+    g = torch.Generator().manual_seed(10 + rank)
+    lr = torch.empty(B, 3, L, L).uniform_(-1, 1, generator=g).to(dev)
+    gt = torch.empty(B, 3, 4 * L, 4 * L).uniform_(-1, 1, generator=g).to(dev)
+
+    l2_loss, cross_ent, tv_loss = losses.MSELoss(), losses.BCELoss(), losses.TVLoss()
+    VGG_loss = losses.perceptual_loss(vgg_net)
+    g_optim = optim.Adam(generator.parameters(), lr=1e-4)
+    d_optim = optim.Adam(discriminator.parameters(), lr=1e-4)
+    real_label = torch.ones((B, 1), device=dev)
+    fake_label = torch.zeros((B, 1), device=dev)
+    parallel.broadcast_parameters(generator)
+    parallel.broadcast_parameters(discriminator)
+
+    def step():
+        output, _ = generator(lr)
+        fake_prob = discriminator(output)
+        real_prob = discriminator(gt)
+        d_loss = cross_ent(real_prob, real_label) + cross_ent(fake_prob, fake_label)
+        g_optim.zero_grad(); d_optim.zero_grad()
+        d_loss.backward()
+        parallel.average_gradients(discriminator.parameters())
+        d_optim.step()
+        output, _ = generator(lr)
+        fake_prob = discriminator(output)
+        _percep, hr_feat, sr_feat = VGG_loss((gt + 1.0) / 2.0, (output + 1.0) / 2.0, layer="relu5_4")
+        g_loss = 0.006 * _percep + 1e-3 * cross_ent(fake_prob, real_label) + \
+            0.0 * tv_loss(0.006 * (hr_feat - sr_feat) ** 2) + l2_loss(output, gt)
+        g_optim.zero_grad(); d_optim.zero_grad()
+        g_loss.backward()
+        parallel.average_gradients(generator.parameters())
+        g_optim.step()
+        return d_loss, g_loss
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        d_loss, g_loss = step()
+    barrier()
+    el = time.perf_counter() - t0
+    from srmi.tiling import max_over_ranks
+    el = max_over_ranks(el, dist, dev)
+    if rank == 0:
+        ms = el / args.steps * 1e3
+        print(json.dumps({"metric": "SRGAN fine-tune steps/sec (whole job)", "value": round(world * args.steps / el, 3),
+                          "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(ms, 3), "hr_mp_per_s": round(world * B * (4 * L) ** 2 / 1e6 / (ms * 1e-3), 3),
+                          "dtype": "f32", "data": "synthetic", "scaling": "weak",
+                          "config": {"workload": f"SRGAN step P/mode.py:148-179, per GPU LR {B}x3x{L}x{L} -> HR {4*L}, "
+                                                 f"D patch {4*L}, VGG19-shaped frozen stack, Adam x2"},
+                          "d_loss": round(float(d_loss), 5), "g_loss": round(float(g_loss), 5)}), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
