@@ -60,7 +60,10 @@ __global__ __launch_bounds__(256, 1) void conv_c64_kernel(C64Params p) {
     const int pl = lane & 15;  // pixel within a 16-pixel tile (MFMA column)
     const int q = lane >> 4;   // k-quarter for operands / channel group for results
 
+    // XCD-aware tile order: consecutive workgroup ids go round-robin to the 8 XCDs (one L2 each), so give each
+    // XCD a CONTIGUOUS run of tiles - vertically adjacent tiles then share their halo rows through one L2.
     int b = blockIdx.x;
+    if ((gridDim.x & 7) == 0 && !(p.dbg & 32)) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
     const int tx = b % p.tiles_x; b /= p.tiles_x;
     const int ty = b % p.tiles_y;
     const int n = b / p.tiles_y;

@@ -57,7 +57,10 @@ __global__ __launch_bounds__(256, 1) void resblock_c64_kernel(ResBlockParams p) 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int pl = lane & 15, q = lane >> 4;
 
+    // XCD-aware tile order: consecutive workgroup ids go round-robin to the 8 XCDs (one L2 each), so give each
+    // XCD a CONTIGUOUS run of tiles - vertically adjacent tiles then share their halo rows through one L2.
     int b = blockIdx.x;
+    if ((gridDim.x & 7) == 0 && !(p.dbg & 32)) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
     const int tx = b % p.tiles_x; b /= p.tiles_x;
     const int ty = b % p.tiles_y;
     const int n = b / p.tiles_y;

@@ -1,0 +1,57 @@
+#!/usr/bin/env python3
+"""Secondary benchmarks (BASELINE configs 2 and 4): SRCNN on 32x1x384x384 and the ESRGAN-style RRDB
+generator on 8x3x256x256, forward only, inputs resident in HBM.  One JSON line per model with ms/step, output MP/s,
+algorithmic TFLOP/s and the kernels the plan selected.  Not the headline metric (bench.py is)."""
+import argparse
+import collections
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "super-resolution_amd")]
+
+import torch
+
+
+def run(name, model, x, out_px, flop_per_step, steps, warmup, compute):
+    model = model.to("cuda:0").eval().set_compute(compute)
+    x = x.to("cuda:0")
+    with torch.no_grad():
+        for _ in range(warmup):
+            model(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            y = model(x)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / steps
+    plan = model._plans.get(model, x.shape[0], x.shape[2], x.shape[3], 1 if compute == "bf16" else 0)
+    print(json.dumps({"workload": name, "compute": compute, "ms_per_step": round(el * 1e3, 3),
+                      "out_mp_per_s": round(out_px / 1e6 / el, 1), "tflops": round(flop_per_step / el / 1e12, 1),
+                      "kernels": dict(collections.Counter(plan.kernels))}), flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--compute", default="bf16")
+    ap.add_argument("--blocks", type=int, default=23)
+    args = ap.parse_args()
+    from srmi.keras_models import SRCNN, RRDBNet
+    g = torch.Generator().manual_seed(0)
+    x2 = torch.rand(32, 1, 384, 384, generator=g)
+    px2 = 32 * 384 * 384
+    run("cfg2 SRCNN 9-3-5 128/64 (reference), 32x1x384x384", SRCNN(), x2, px2, px2 * 171_392.0, args.steps, args.warmup, args.compute)
+    run("cfg2 SRCNN 9-1-5 64/32 (BASELINE), 32x1x384x384", SRCNN(k=(9, 1, 5), ch=(64, 32)), x2, px2, px2 * 16_064.0,
+        args.steps, args.warmup, args.compute)
+    x4 = torch.rand(8, 3, 256, 256, generator=g) * 2 - 1
+    lr_px = 8 * 256 * 256
+    run(f"cfg4 RRDBNet {args.blocks} blocks, 8x3x256x256 -> x4", RRDBNet(num_blocks=args.blocks), x4, lr_px * 16,
+        lr_px * 2.0 * (175_104 * args.blocks + 803_520), args.steps, args.warmup, args.compute)
+
+
+if __name__ == "__main__":
+    main()
