@@ -105,6 +105,7 @@ int conv_geom(const srmi_conv_desc& d, ConvGeom* g) {
 
 int select_kernel(const srmi_conv_desc& d) {
     if (c64_supported(d)) return K_C64_BF16;
+    if (cin_supported(d)) return K_CIN_BF16;
     if (thin_supported(d)) return K_THIN_BF16;
     if (k9c3_supported(d)) return K_K9C3_BF16;
     return K_GENERIC_F32;
@@ -115,6 +116,7 @@ const char* kernel_label(int k) {
         case K_C64_BF16: return "c64_bf16";
         case K_THIN_BF16: return "c64_thin_bf16";
         case K_K9C3_BF16: return "k9c3_bf16";
+        case K_CIN_BF16: return "cin_bf16";
         default: return "generic_f32";
     }
 }
@@ -141,6 +143,7 @@ static int conv_fwd_one(const srmi_conv_args* a, hipStream_t s) {
         case K_C64_BF16: return c64_launch(*a, g, s);
         case K_THIN_BF16: return thin_launch(*a, g, s);   // rejects a residual (SRMI_EUNSUPPORTED)
         case K_K9C3_BF16: return k9c3_launch(*a, g, s);
+        case K_CIN_BF16: return cin_launch(*a, g, s);
         default: return generic_launch(*a, g, s);
     }
 }
@@ -173,6 +176,7 @@ int srmi_conv2d_packed_weight_bytes(const srmi_conv_desc* d, size_t* bytes) {
         case K_C64_BF16: *bytes = c64_packed_bytes(*d); break;
         case K_THIN_BF16: *bytes = thin_packed_bytes(*d); break;
         case K_K9C3_BF16: *bytes = k9c3_packed_bytes(*d); break;
+        case K_CIN_BF16: *bytes = cin_packed_bytes(*d); break;
         default: *bytes = generic_packed_bytes(*d);
     }
     return SRMI_OK;
@@ -188,6 +192,7 @@ int srmi_conv2d_pack_weights(const srmi_conv_desc* d, const float* w_oihw, void*
         case K_C64_BF16: return c64_pack(*d, w_oihw, w_packed, s);
         case K_THIN_BF16: return thin_pack(*d, w_oihw, w_packed, s);
         case K_K9C3_BF16: return k9c3_pack(*d, w_oihw, w_packed, s);
+        case K_CIN_BF16: return cin_pack(*d, w_oihw, w_packed, s);
         default: return generic_pack(*d, w_oihw, w_packed, s);
     }
 }

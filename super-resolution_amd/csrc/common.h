@@ -56,7 +56,7 @@ int conv_geom(const srmi_conv_desc& d, ConvGeom* g);  // validates, fills g
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
 // kernel families (dispatch.cpp decides, the .hip files implement)
-enum Kernel { K_GENERIC_F32 = 0, K_C64_BF16 = 1, K_THIN_BF16 = 2, K_K9C3_BF16 = 3 };
+enum Kernel { K_GENERIC_F32 = 0, K_C64_BF16 = 1, K_THIN_BF16 = 2, K_K9C3_BF16 = 3, K_CIN_BF16 = 4 };
 const char* kernel_label(int k);
 int select_kernel(const srmi_conv_desc& d);
 
@@ -82,6 +82,12 @@ bool k9c3_supported(const srmi_conv_desc& d);
 size_t k9c3_packed_bytes(const srmi_conv_desc& d);
 int k9c3_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s);
 int k9c3_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s);
+
+// bf16 MFMA kernel for 3x3 / Cin % 32 == 0 / Cout % 32 == 0, K-chunked (conv_cin_bf16.hip): dense blocks, wide layers
+bool cin_supported(const srmi_conv_desc& d);
+size_t cin_packed_bytes(const srmi_conv_desc& d);
+int cin_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s);
+int cin_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s);
 
 // fused ResBlock (conv_resblock_bf16.hip)
 bool resblock_supported(const srmi_conv_desc& d1, const srmi_conv_desc& d2);

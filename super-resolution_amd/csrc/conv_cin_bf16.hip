@@ -1,0 +1,345 @@
+// conv3x3 / stride 1 / pad 1, NHWC bf16, ANY Cin that is a multiple of 32 and Cout a multiple of 32, on
+// v_mfma_f32_16x16x32_bf16: the wide-input sibling of conv_c64_bf16.hip.
+//
+// Serves the layers the Cin = 64 kernel cannot: the ESRGAN-style dense block (ESRGAN/untitled0.py:18-35:
+// 64/96/128 -> 32 with the input a channel slice of the 160-channel concat buffer, 160 -> 64 with the block
+// input as a channel-slice residual), SRCNN's 128 -> 64 (SRCNN/srcnn.py:205) and VGG / discriminator widths.
+//
+// Same machinery as conv_c64_bf16.hip (one workgroup = 4 waves = one TH x TW tile; activations are the MFMA B
+// operand read from an XOR-swizzled LDS tile; weights are pre-packed A fragments streamed through a 4-slot
+// LDS-DMA ring with a counted-vmcnt hand-off per tap), with two differences:
+//   * the contraction runs over K-CHUNKS of 64 input channels: the halo tile of one chunk is staged, its
+//     9 taps x 2 k-steps are accumulated, the next chunk is staged over it; accumulators live across chunks
+//     (Cin = 96 / 160: the last chunk's upper 32 channels are zero-filled, their packed weights are zero);
+//   * NCT = 4 or 2 channel tiles per workgroup (64 or 32 output channels); more output channels = more
+//     workgroups along grid.y, each re-reading the tile (L2-resident).
+// The chunk hand-off is synchronous (stage -> barrier -> compute): ~60 % of the Cin = 64 kernel's rate, 8-10x the
+// generic f32 kernel's.
+#include <stdlib.h>
+
+#include "c64_common.h"
+
+namespace srmi {
+
+struct CinParams {
+    const bf16_t* x; const bf16_t* w;
+    const float* scale; const float* shift; const float* alpha;
+    const bf16_t* res; bf16_t* y;
+    int N, H, W, Cin, Cout, kchunks, in_cs, out_cs, out_co, res_cs;
+    int act; float act_param; int alpha_pc;
+    int tiles_x, tiles_y;
+};
+
+constexpr int CIN_WRING = 4;
+
+template <int TH, int TWT, int NCT>
+__global__ __launch_bounds__(256, 1) void conv_cin_kernel(CinParams p) {
+    constexpr int TW = TWT * 16;
+    constexpr int NPT = TH * TWT;
+    static_assert(NPT % 4 == 0, "pixel tiles must split evenly over 4 waves");
+    constexpr int PT = NPT / 4;
+    constexpr int ROWP = (TW + 2 + 15) / 16 * 16;
+    constexpr int IN_BYTES = (TH + 2) * ROWP * 128;
+    constexpr int TAP_BYTES = 2 * NCT * 1024;          // 2 k-steps x NCT channel tiles x 64 lanes x 16 B
+    constexpr int WAVE_BYTES = TAP_BYTES / 4;          // each wave moves a quarter of every tap
+    constexpr int NDMA = WAVE_BYTES / 1024;            // LDS-DMA instructions per wave and tap (2 or 1)
+    constexpr int CG = NCT * 16;                       // output channels of this workgroup
+    __shared__ __attribute__((aligned(16))) unsigned char lds[IN_BYTES + CIN_WRING * TAP_BYTES + 3 * 64 * 4];
+    unsigned char* const wring = lds + IN_BYTES;
+    float* const par = (float*)(lds + IN_BYTES + CIN_WRING * TAP_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 15, q = lane >> 4;
+
+    int b = blockIdx.x;
+    if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);   // XCD-aware tile order
+    const int tx = b % p.tiles_x; b /= p.tiles_x;
+    const int ty = b % p.tiles_y;
+    const int n = b / p.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int cg = blockIdx.y;                         // output-channel group
+    const int co0 = cg * CG;
+
+    // ---- weight stream: tap index g = kc * 9 + tap of this channel group ------------------------------
+    const int ntap = p.kchunks * 9;
+    const unsigned char* wsrc = (const unsigned char*)p.w + (size_t)cg * ntap * TAP_BYTES + wave * WAVE_BYTES + lane * 16;
+    const unsigned wring_lds = (unsigned)(uintptr_t)(lptr_t)wring;
+    auto issue_tap = [&](int g) {
+        const unsigned char* src = wsrc + (size_t)g * TAP_BYTES;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(
+            wring_lds + (unsigned)((g & (CIN_WRING - 1)) * TAP_BYTES + wave * WAVE_BYTES));
+        unsigned keep;
+        if constexpr (NDMA == 2) {
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %3\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %1, off\n\t"
+                "s_add_u32 m0, m0, 0x400\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %2, off\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(src), "v"(src + 1024), "s"(dst)
+                : "memory", "scc");
+        } else {
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %2\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %1, off\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(src), "s"(dst)
+                : "memory");
+        }
+    };
+    issue_tap(0);
+    issue_tap(1);
+    issue_tap(2);
+
+    // epilogue parameters of this group's CG channels, in kernel channel order (= conv channel order here)
+    if (tid < CG) {
+        const int co = co0 + tid;
+        float sl = 1.f;
+        if (p.act == SRMI_ACT_RELU) sl = 0.f;
+        else if (p.act == SRMI_ACT_LRELU) sl = p.act_param;
+        else if (p.act == SRMI_ACT_PRELU) sl = p.alpha[p.alpha_pc ? co : 0];
+        par[tid] = p.scale[co];
+        par[64 + tid] = p.shift[co];
+        par[128 + tid] = sl;
+    }
+
+    int prow[PT], pcol[PT];
+#pragma unroll
+    for (int k = 0; k < PT; ++k) {
+        const int t = wave * PT + k;
+        prow[k] = t / TWT;
+        pcol[k] = (t - prow[k] * TWT) * 16;
+    }
+    int boff[PT][3];
+#pragma unroll
+    for (int k = 0; k < PT; ++k)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int P = prow[k] * ROWP + pcol[k] + pl + dx;
+            boff[k][dx] = P * 128 + ((q ^ ((P >> 1) & 7)) << 4);
+        }
+
+    f32x4 acc[PT][NCT];
+#pragma unroll
+    for (int k = 0; k < PT; ++k)
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) acc[k][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const bf16_t* xin = p.x + (size_t)n * p.H * p.W * p.in_cs;
+    for (int kc = 0; kc < p.kchunks; ++kc) {
+        // ---- stage the halo tile of input channels [64 kc, 64 kc + 64) -----------------------------
+        if (kc > 0) __builtin_amdgcn_s_barrier();      // every wave has consumed the previous chunk's tile
+        {
+            constexpr int NCH = (TH + 2) * (TW + 2) * 8;
+            constexpr int NIT = (NCH + 255) / 256;
+            const int cvalid = min(p.Cin - kc * 64, 64) >> 3;      // 16-B channel chunks that exist (8 or 4)
+            u32x4 v[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = min(tid + it * 256, NCH - 1);
+                const int pp = idx >> 3, ch = idx & 7;
+                const int row = pp / (TW + 2), col = pp - row * (TW + 2);
+                const int gy = min(max(y0 - 1 + row, 0), p.H - 1), gx = min(max(x0 - 1 + col, 0), p.W - 1);
+                const int chc = ch < cvalid ? ch : 0;              // clamped: never reads past the pixel's channels
+                v[it] = *(const u32x4*)(xin + ((size_t)gy * p.W + gx) * p.in_cs + kc * 64 + chc * 8);
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + it * 256;
+                const int pp = idx >> 3, ch = idx & 7;
+                const int row = pp / (TW + 2), col = pp - row * (TW + 2);
+                const int gy = y0 - 1 + row, gx = x0 - 1 + col;
+                const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W && ch < cvalid;
+                u32x4 z = v[it];
+                if (!ok) z = (u32x4){0u, 0u, 0u, 0u};
+                const int P = row * ROWP + col;
+                if (idx < NCH) *(u32x4*)(lds + P * 128 + ((ch ^ ((P >> 1) & 7)) << 4)) = z;
+            }
+        }
+        // tile written; the loads' vmcnt(0) also retired every weight tap issued so far
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+
+        bf16x8 afr[2][NCT], bfr[2][PT];
+        {
+            const unsigned char* wslot = wring + ((kc * 9) & (CIN_WRING - 1)) * TAP_BYTES + lane * 16;
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) afr[0][t] = *(const bf16x8*)(wslot + t * 1024);
+#pragma unroll
+            for (int k = 0; k < PT; ++k) bfr[0][k] = *(const bf16x8*)(lds + boff[k][0]);
+        }
+#pragma unroll
+        for (int j = 0; j < 18; ++j) {
+            const int tap = j >> 1, half = j & 1;
+            const int g = kc * 9 + tap;
+            if (half == 1) {
+                // tap g+1 landed (own copy: counted vmcnt, tap g+2 may stay in flight; others': barrier);
+                // the barrier also retires every wave's reads of tap g-1, whose slot tap g+3 re-uses
+                if (g + 2 < ntap) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (g + 3 < ntap) issue_tap(g + 3);
+            }
+            if (j + 1 < 18) {
+                const int tapn = (j + 1) >> 1, halfn = (j + 1) & 1;
+                const int dyn = tapn / 3, dxn = tapn - 3 * dyn;
+                const unsigned char* wslot =
+                    wring + ((kc * 9 + tapn) & (CIN_WRING - 1)) * TAP_BYTES + lane * 16 + halfn * (NCT * 1024);
+#pragma unroll
+                for (int t = 0; t < NCT; ++t) afr[(j + 1) & 1][t] = *(const bf16x8*)(wslot + t * 1024);
+#pragma unroll
+                for (int k = 0; k < PT; ++k)
+                    bfr[(j + 1) & 1][k] =
+                        *(const bf16x8*)(lds + ((boff[k][dxn] ^ (halfn << 6)) + dyn * (ROWP * 128)));
+            }
+#pragma unroll
+            for (int k = 0; k < PT; ++k)
+#pragma unroll
+                for (int t = 0; t < NCT; ++t)
+                    acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[j & 1][t], bfr[j & 1][k], acc[k][t], 0, 0, 0);
+            if (j + 1 < 18) sched_interleave<0, NCT + PT, NCT * PT>();
+        }
+    }
+
+    // ---- epilogue: scale/shift -> slope activation -> + residual (channel-slice strides) -> bf16 store ----
+    // channel map (cin_row_to_cl): lane (pl, q) holds, of channel tile t, rows 4q..4q+3; with NCT = 4 these are
+    // channels 8q..8q+7 and 32+8q..32+8q+7 of the group (two 16-B stores), with NCT = 2 channels 8q..8q+7 (one).
+    constexpr int NH = NCT / 2;                        // 8-channel runs per lane
+    float sc[8 * NH], sh[8 * NH], sl[8 * NH];
+#pragma unroll
+    for (int hi = 0; hi < NH; ++hi)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = 32 * hi + 8 * q + e;
+            sc[8 * hi + e] = par[c];
+            sh[8 * hi + e] = par[64 + c];
+            sl[8 * hi + e] = par[128 + c];
+        }
+    int opaque0;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));
+#pragma unroll
+    for (int k = 0; k < PT; ++k) {
+        const int oy = y0 + prow[k], ox = x0 + pcol[k] + pl + opaque0;
+        if (!(oy < p.H && ox < p.W)) continue;
+        const size_t pix = ((size_t)n * p.H + oy) * p.W + ox;
+#pragma unroll
+        for (int hi = 0; hi < NH; ++hi) {
+            float v[8];
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 8 * hi + 4 * tt + e;
+                    const float z = acc[k][2 * hi + tt][e] * sc[c] + sh[c];
+                    v[4 * tt + e] = z >= 0.f ? z : z * sl[c];
+                }
+            const int cch = co0 + 32 * hi + 8 * q;
+            if (p.res) {
+                const u32x4 r = *(const u32x4*)(p.res + pix * p.res_cs + cch);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v[2 * e] += bf2f((bf16_t)(r[e] & 0xffffu));
+                    v[2 * e + 1] += bf2f((bf16_t)(r[e] >> 16));
+                }
+            }
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+            *(u32x4*)(p.y + pix * p.out_cs + p.out_co + cch) = o;
+        }
+    }
+}
+
+// A-row r (0..15) of channel tile t (0..NCT-1) -> channel within the group
+__host__ __device__ __forceinline__ int cin_row_to_cl(int t, int r) { return 32 * (t >> 1) + 8 * (r >> 2) + 4 * (t & 1) + (r & 3); }
+
+// OIHW f32 -> bf16 A fragments:  packed[((((cg*KC + kc)*18 + ks)*NCT + t)*64 + lane)*8 + j] = W[co][ci][ky][kx],
+//   tap = ks>>1, ci = 64 kc + 32 (ks&1) + 8 (lane>>4) + j (zero when >= Cin), co = cg*16*NCT + cin_row_to_cl(t, lane&15)
+__global__ void cin_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cin, int KC, int NCT,
+                                size_t total) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int j = (int)(idx & 7);
+        const int lane = (int)((idx >> 3) & 63);
+        size_t rest = idx >> 9;
+        const int t = (int)(rest % NCT); rest /= NCT;
+        const int ks = (int)(rest % 18); rest /= 18;
+        const int kc = (int)(rest % KC);
+        const int cg = (int)(rest / KC);
+        const int co = cg * 16 * NCT + cin_row_to_cl(t, lane & 15);
+        const int ci = 64 * kc + 32 * (ks & 1) + 8 * (lane >> 4) + j;
+        const int tap = ks >> 1;
+        out[idx] = ci < Cin ? f2bf(w[((size_t)co * Cin + ci) * 9 + tap]) : (bf16_t)0;
+    }
+}
+
+static int cin_nct(const srmi_conv_desc& d) { return d.Cout % 64 == 0 ? 4 : 2; }
+static int cin_kchunks(const srmi_conv_desc& d) { return (d.Cin + 63) / 64; }
+
+bool cin_supported(const srmi_conv_desc& d) {
+    if (d.compute != SRMI_COMPUTE_BF16) return false;
+    if (d.kh != 3 || d.kw != 3 || d.stride != 1 || d.pad != 1 || d.shuffle != 1) return false;
+    if (d.Cin % 32 != 0 || d.Cin < 32 || d.Cin > 1024 || d.Cout % 32 != 0 || d.Cout > 1024) return false;
+    if (d.in_dtype != SRMI_BF16 || d.out_dtype != SRMI_BF16) return false;
+    if (d.in_layout != SRMI_NHWC || d.out_layout != SRMI_NHWC) return false;
+    if (d.act == SRMI_ACT_TANH || d.act == SRMI_ACT_SIGMOID) return false;
+    const int in_cs = d.in_cstride ? d.in_cstride : d.Cin;
+    const int out_cs = d.out_cstride ? d.out_cstride : d.Cout;
+    const int res_cs = d.res_cstride ? d.res_cstride : d.Cout;
+    if (in_cs % 8 != 0 || out_cs % 8 != 0 || d.out_coffset % 8 != 0 || res_cs % 8 != 0) return false;
+    return true;
+}
+
+size_t cin_packed_bytes(const srmi_conv_desc& d) {
+    return (size_t)d.Cout * cin_kchunks(d) * 64 * 9 * sizeof(bf16_t);
+}
+
+int cin_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s) {
+    const size_t total = (size_t)d.Cout * cin_kchunks(d) * 64 * 9;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(cin_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w_oihw, (bf16_t*)w_packed, d.Cin,
+                       cin_kchunks(d), cin_nct(d), total);
+    return hip_check(hipGetLastError(), "cin_pack_kernel");
+}
+
+int cin_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
+    const srmi_conv_desc& d = a.d;
+    if (((uintptr_t)a.x | (uintptr_t)a.y | (uintptr_t)a.w | (uintptr_t)a.residual) & 15) {
+        set_error("cin_bf16: x, w, y and residual must be 16-byte aligned");
+        return SRMI_EINVAL;
+    }
+    if (a.residual && d.res_dtype != SRMI_BF16) { set_error("cin_bf16: residual must be bf16"); return SRMI_EUNSUPPORTED; }
+    CinParams p;
+    p.x = (const bf16_t*)a.x; p.w = (const bf16_t*)a.w;
+    p.scale = a.scale; p.shift = a.shift; p.alpha = a.alpha;
+    p.res = (const bf16_t*)a.residual; p.y = (bf16_t*)a.y;
+    p.N = d.N; p.H = d.H; p.W = d.W; p.Cin = d.Cin; p.Cout = d.Cout; p.kchunks = cin_kchunks(d);
+    p.in_cs = g.in_cs; p.out_cs = g.out_cs; p.out_co = d.out_coffset; p.res_cs = g.res_cs;
+    p.act = d.act; p.act_param = d.act_param; p.alpha_pc = d.alpha_per_channel;
+    if (d.N == 0 || d.H == 0 || d.W == 0) return SRMI_OK;
+    const int nct = cin_nct(d);
+    const unsigned gy = (unsigned)(d.Cout / (16 * nct));
+    const bool big = d.W > 64 && d.H >= 6;
+    if (big) { p.tiles_x = (d.W + 95) / 96; p.tiles_y = (d.H + 5) / 6; }
+    else { p.tiles_x = (d.W + 31) / 32; p.tiles_y = (d.H + 3) / 4; }
+    const long long nb = (long long)d.N * p.tiles_x * p.tiles_y;
+    if (nb > 0x7fffffffLL || gy > 65535u) { set_error("cin_bf16: grid too large"); return SRMI_EINVAL; }
+    const dim3 grid((unsigned)nb, gy);
+    if (big && nct == 4) hipLaunchKernelGGL((conv_cin_kernel<6, 6, 4>), grid, dim3(256), 0, s, p);
+    else if (big) hipLaunchKernelGGL((conv_cin_kernel<6, 6, 2>), grid, dim3(256), 0, s, p);
+    else if (nct == 4) hipLaunchKernelGGL((conv_cin_kernel<4, 2, 4>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv_cin_kernel<4, 2, 2>), grid, dim3(256), 0, s, p);
+    return hip_check(hipGetLastError(), "conv_cin_kernel");
+}
+
+}  // namespace srmi

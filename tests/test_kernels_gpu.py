@@ -46,7 +46,7 @@ def _ref_fused(x_nchw, w, scale, shift, act, act_param, alpha, residual_nchw, st
 
 def _run_case(N, H, W, Cin, Cout, k, *, stride=1, act=L.ACT_NONE, act_param=0.0, alpha_pc=0, residual=False, r=1,
               dcr=False, io=torch.float32, compute=L.COMPUTE_F32, in_layout=L.NHWC, out_layout=L.NHWC,
-              in_cs=0, out_cs=0, out_co=0, seed=0):
+              in_cs=0, out_cs=0, out_co=0, res_cs=0, seed=0):
     g = _rng(seed)
     x = torch.from_numpy(g.uniform(-1, 1, (N, Cin, H, W)).astype(np.float32))
     w = torch.from_numpy((g.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32))
@@ -72,7 +72,7 @@ def _run_case(N, H, W, Cin, Cout, k, *, stride=1, act=L.ACT_NONE, act_param=0.0,
     desc = Fn.make_desc(N, H, W, Cin, Cout, k, stride=stride, in_dtype=dio, out_dtype=dio, res_dtype=dio,
                         in_layout=in_layout, out_layout=out_layout, compute=compute, act=act, act_param=act_param,
                         alpha_per_channel=alpha_pc, shuffle=r, shuffle_order=L.SHUFFLE_DCR if dcr else L.SHUFFLE_CRD,
-                        in_cstride=in_cs, out_cstride=out_cs, out_coffset=out_co)
+                        in_cstride=in_cs, out_cstride=out_cs, out_coffset=out_co, res_cstride=res_cs)
     # device buffers
     if in_layout == L.NHWC:
         cs = in_cs or Cin
@@ -86,6 +86,10 @@ def _run_case(N, H, W, Cin, Cout, k, *, stride=1, act=L.ACT_NONE, act_param=0.0,
         ocs = out_cs or Cf
         yd = torch.full((N, Ho * r, Wo * r, ocs), -5.0, dtype=io, device=DEV)
         rd = res.permute(0, 2, 3, 1).contiguous().to(io).to(DEV) if residual else None
+        if residual and res_cs:                                  # residual = leading channels of a wider buffer
+            wide = torch.full((N, Ho * r, Wo * r, res_cs), 9.0, dtype=io, device=DEV)
+            wide[..., :Cf] = rd
+            rd = wide
     else:
         yd = torch.full((N, Cf, Ho * r, Wo * r), -5.0, dtype=io, device=DEV)
         rd = res.to(io).to(DEV) if residual else None
@@ -171,6 +175,24 @@ def test_generic_kernel_bf16_storage(case):
 def test_c64_bf16_kernel(case):
     name = _run_case(Cin=64, k=3, io=torch.bfloat16, compute=L.COMPUTE_BF16, **case)
     assert name == "c64_bf16"
+
+
+@pytest.mark.parametrize("case", [
+    # the ESRGAN-style dense block (ESRGAN/untitled0.py:18-35): inputs and outputs are slices of one 160-ch buffer
+    dict(N=1, H=9, W=11, Cin=64, Cout=32, act=L.ACT_LRELU, act_param=0.2, in_cs=160, out_cs=160, out_co=64),
+    dict(N=1, H=9, W=11, Cin=96, Cout=32, act=L.ACT_LRELU, act_param=0.2, in_cs=160, out_cs=160, out_co=96),
+    dict(N=2, H=8, W=33, Cin=128, Cout=32, act=L.ACT_LRELU, act_param=0.2, in_cs=160, out_cs=160, out_co=128),
+    dict(N=1, H=9, W=11, Cin=160, Cout=64, residual=True, res_cs=160),        # compress conv + x (slice residual)
+    dict(N=1, H=13, W=100, Cin=160, Cout=64, residual=True, res_cs=160),      # big 6x96 tile, ragged
+    dict(N=1, H=12, W=97, Cin=96, Cout=32, act=L.ACT_LRELU, act_param=0.2),   # dense (no slices), big tile
+    dict(N=1, H=7, W=70, Cin=128, Cout=64, act=L.ACT_RELU),                   # SRCNN conv2 (SRCNN/srcnn.py:205)
+    dict(N=1, H=6, W=10, Cin=256, Cout=128, act=L.ACT_PRELU, alpha_pc=1),     # 4 K-chunks, 2 channel groups
+    dict(N=1, H=5, W=6, Cin=32, Cout=96, act=L.ACT_PRELU),                    # half chunk only, 3 groups of 32
+    dict(N=2, H=6, W=96, Cin=512, Cout=64, act=L.ACT_RELU),                   # VGG-width contraction
+])
+def test_cin_bf16_kernel(case):
+    name = _run_case(k=3, io=torch.bfloat16, compute=L.COMPUTE_BF16, **case)
+    assert name == "cin_bf16"
 
 
 @pytest.mark.parametrize("case", [
