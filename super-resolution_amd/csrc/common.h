@@ -55,6 +55,20 @@ int conv_geom(const srmi_conv_desc& d, ConvGeom* g);  // validates, fills g
 
 static inline int round_up(int a, int b) { return (a + b - 1) / b * b; }
 
+// Spatial tile choice of the LDS-tiled 3x3 kernels: 0 = 6 x 96, 1 = 8 x 64, 2 = 4 x 32.  Cost = rounds of 256
+// workgroups x tile area (ragged edges and a partly filled last round are both paid for); the small tile keeps
+// one wave per SIMD busy only a quarter as well, so it is chosen only when it is >1.5x cheaper.
+static inline int pick_tile3x3(int N, int H, int W) {
+    static const int th[3] = {6, 8, 4}, tw[3] = {96, 64, 32};
+    double best = 0; int bi = 0;
+    for (int i = 0; i < 3; ++i) {
+        const long long wg = (long long)N * ((H + th[i] - 1) / th[i]) * ((W + tw[i] - 1) / tw[i]);
+        double cost = (double)((wg + 255) / 256) * th[i] * tw[i] * (i == 2 ? 1.5 : 1.0);
+        if (i == 0 || cost < best) { best = cost; bi = i; }
+    }
+    return bi;
+}
+
 // kernel families (dispatch.cpp decides, the .hip files implement)
 enum Kernel { K_GENERIC_F32 = 0, K_C64_BF16 = 1, K_THIN_BF16 = 2, K_K9C3_BF16 = 3, K_CIN_BF16 = 4 };
 const char* kernel_label(int k);

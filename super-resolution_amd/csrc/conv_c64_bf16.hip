@@ -294,20 +294,16 @@ int c64_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     p.N = d.N; p.H = d.H; p.W = d.W; p.nchunk = d.Cout / 64; p.in_cs = g.in_cs;
     { const char* e = getenv("SRMI_DBG"); p.dbg = e ? atoi(e) : 0; }
     if (d.N == 0 || d.H == 0 || d.W == 0) return SRMI_OK;
-    // tile choice: 6 x 96 (9 pixel tiles per wave) when the image is wide enough to fill it,
-    // otherwise 4 x 32 (2 pixel tiles per wave) so small images still spread over the CUs.
-    const bool big = d.W > 64 && d.H >= 6;
-    if (big) {
-        p.tiles_x = (d.W + 95) / 96; p.tiles_y = (d.H + 5) / 6;
-        const long long nb = (long long)d.N * p.tiles_x * p.tiles_y;
-        if (nb > 0x7fffffffLL) { set_error("c64_bf16: grid too large"); return SRMI_EINVAL; }
-        hipLaunchKernelGGL((conv_c64_kernel<6, 6>), dim3((unsigned)nb), dim3(256), 0, s, p);
-    } else {
-        p.tiles_x = (d.W + 31) / 32; p.tiles_y = (d.H + 3) / 4;
-        const long long nb = (long long)d.N * p.tiles_x * p.tiles_y;
-        if (nb > 0x7fffffffLL) { set_error("c64_bf16: grid too large"); return SRMI_EINVAL; }
-        hipLaunchKernelGGL((conv_c64_kernel<4, 2>), dim3((unsigned)nb), dim3(256), 0, s, p);
-    }
+    // tile choice (pick_tile3x3): 6 x 96 (9 pixel tiles per wave), 8 x 64 (8 per wave) or 4 x 32 (2 per wave),
+    // whichever wastes the fewest workgroup-rounds on ragged edges and a partly filled last round.
+    const int tile = pick_tile3x3(d.N, d.H, d.W);
+    static const int th[3] = {6, 8, 4}, tw[3] = {96, 64, 32};
+    p.tiles_x = (d.W + tw[tile] - 1) / tw[tile]; p.tiles_y = (d.H + th[tile] - 1) / th[tile];
+    const long long nb = (long long)d.N * p.tiles_x * p.tiles_y;
+    if (nb > 0x7fffffffLL) { set_error("c64_bf16: grid too large"); return SRMI_EINVAL; }
+    if (tile == 0) hipLaunchKernelGGL((conv_c64_kernel<6, 6>), dim3((unsigned)nb), dim3(256), 0, s, p);
+    else if (tile == 1) hipLaunchKernelGGL((conv_c64_kernel<8, 4>), dim3((unsigned)nb), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv_c64_kernel<4, 2>), dim3((unsigned)nb), dim3(256), 0, s, p);
     return hip_check(hipGetLastError(), "conv_c64_kernel");
 }
 

@@ -329,14 +329,16 @@ int cin_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     if (d.N == 0 || d.H == 0 || d.W == 0) return SRMI_OK;
     const int nct = cin_nct(d);
     const unsigned gy = (unsigned)(d.Cout / (16 * nct));
-    const bool big = d.W > 64 && d.H >= 6;
-    if (big) { p.tiles_x = (d.W + 95) / 96; p.tiles_y = (d.H + 5) / 6; }
-    else { p.tiles_x = (d.W + 31) / 32; p.tiles_y = (d.H + 3) / 4; }
+    const int tile = pick_tile3x3(d.N, d.H, d.W);
+    static const int th[3] = {6, 8, 4}, tw[3] = {96, 64, 32};
+    p.tiles_x = (d.W + tw[tile] - 1) / tw[tile]; p.tiles_y = (d.H + th[tile] - 1) / th[tile];
     const long long nb = (long long)d.N * p.tiles_x * p.tiles_y;
     if (nb > 0x7fffffffLL || gy > 65535u) { set_error("cin_bf16: grid too large"); return SRMI_EINVAL; }
     const dim3 grid((unsigned)nb, gy);
-    if (big && nct == 4) hipLaunchKernelGGL((conv_cin_kernel<6, 6, 4>), grid, dim3(256), 0, s, p);
-    else if (big) hipLaunchKernelGGL((conv_cin_kernel<6, 6, 2>), grid, dim3(256), 0, s, p);
+    if (tile == 0 && nct == 4) hipLaunchKernelGGL((conv_cin_kernel<6, 6, 4>), grid, dim3(256), 0, s, p);
+    else if (tile == 0) hipLaunchKernelGGL((conv_cin_kernel<6, 6, 2>), grid, dim3(256), 0, s, p);
+    else if (tile == 1 && nct == 4) hipLaunchKernelGGL((conv_cin_kernel<8, 4, 4>), grid, dim3(256), 0, s, p);
+    else if (tile == 1) hipLaunchKernelGGL((conv_cin_kernel<8, 4, 2>), grid, dim3(256), 0, s, p);
     else if (nct == 4) hipLaunchKernelGGL((conv_cin_kernel<4, 2, 4>), grid, dim3(256), 0, s, p);
     else hipLaunchKernelGGL((conv_cin_kernel<4, 2, 2>), grid, dim3(256), 0, s, p);
     return hip_check(hipGetLastError(), "conv_cin_kernel");

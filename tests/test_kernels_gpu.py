@@ -171,6 +171,8 @@ def test_generic_kernel_bf16_storage(case):
     dict(N=1, H=7, W=9, Cout=256, act=L.ACT_PRELU, alpha_pc=1, r=2, dcr=True),  # depth_to_space store (DCR)
     dict(N=1, H=9, W=20, Cout=128, act=L.ACT_LRELU, act_param=0.01),          # D conv 64->128
     dict(N=1, H=8, W=8, Cout=64, act=L.ACT_LRELU, act_param=0.2, in_cs=160, out_cs=160, out_co=64),  # concat slices
+    dict(N=1, H=15, W=120, Cout=64, act=L.ACT_PRELU, residual=True),          # 8 x 64 tile (fewer rounds), ragged
+    dict(N=1, H=16, W=128, Cout=256, act=L.ACT_PRELU, r=2),                   # 8 x 64 tile + PixelShuffle store
 ])
 def test_c64_bf16_kernel(case):
     name = _run_case(Cin=64, k=3, io=torch.bfloat16, compute=L.COMPUTE_BF16, **case)
@@ -189,6 +191,8 @@ def test_c64_bf16_kernel(case):
     dict(N=1, H=6, W=10, Cin=256, Cout=128, act=L.ACT_PRELU, alpha_pc=1),     # 4 K-chunks, 2 channel groups
     dict(N=1, H=5, W=6, Cin=32, Cout=96, act=L.ACT_PRELU),                    # half chunk only, 3 groups of 32
     dict(N=2, H=6, W=96, Cin=512, Cout=64, act=L.ACT_RELU),                   # VGG-width contraction
+    dict(N=1, H=15, W=120, Cin=160, Cout=64, residual=True, res_cs=160),      # 8 x 64 tile, ragged
+    dict(N=1, H=16, W=128, Cin=96, Cout=32, act=L.ACT_LRELU, act_param=0.2, in_cs=160, out_cs=160, out_co=96),
 ])
 def test_cin_bf16_kernel(case):
     name = _run_case(k=3, io=torch.bfloat16, compute=L.COMPUTE_BF16, **case)
