@@ -181,18 +181,21 @@ bool k9c3_supported(const srmi_conv_desc& d) {
     if (d.compute != SRMI_COMPUTE_BF16) return false;
     if (d.res_cstride && d.res_cstride != d.Cout / (d.shuffle * d.shuffle)) return false;   // dense residual only
     if (d.kh != 9 || d.kw != 9 || d.stride != 1 || d.pad != 4) return false;
-    if (d.Cin < 1 || d.Cin > 3 || d.Cout != 64 || d.shuffle != 1) return false;
+    if (d.Cin < 1 || d.Cin > 3 || d.Cout % 64 != 0 || d.Cout > 512 || d.shuffle != 1) return false;
     if (d.out_dtype != SRMI_BF16 || d.out_layout != SRMI_NHWC) return false;
     if (d.act == SRMI_ACT_TANH || d.act == SRMI_ACT_SIGMOID) return false;
-    const int out_cs = d.out_cstride ? d.out_cstride : 64;
+    const int out_cs = d.out_cstride ? d.out_cstride : d.Cout;
     if (out_cs % 8 != 0 || d.out_coffset % 8 != 0) return false;
     return true;
 }
 
-size_t k9c3_packed_bytes(const srmi_conv_desc&) { return K9_W_BYTES; }
+// Cout = 64 m runs as m launches of the 64-channel kernel (the input is 1-3 channels: re-reading it is free)
+size_t k9c3_packed_bytes(const srmi_conv_desc& d) { return (size_t)(d.Cout / 64) * K9_W_BYTES; }
 
 int k9c3_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s) {
-    hipLaunchKernelGGL(k9c3_pack_kernel, dim3(144), dim3(256), 0, s, w_oihw, (bf16_t*)w_packed, d.Cin);
+    for (int c = 0; c < d.Cout / 64; ++c)
+        hipLaunchKernelGGL(k9c3_pack_kernel, dim3(144), dim3(256), 0, s, w_oihw + (size_t)c * 64 * d.Cin * 81,
+                           (bf16_t*)((unsigned char*)w_packed + (size_t)c * K9_W_BYTES), d.Cin);
     return hip_check(hipGetLastError(), "k9c3_pack_kernel");
 }
 
@@ -203,11 +206,13 @@ int k9c3_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
         return SRMI_EINVAL;
     }
     if (a.residual && d.res_dtype != SRMI_BF16) { set_error("k9c3_bf16: residual must be bf16"); return SRMI_EUNSUPPORTED; }
+    for (int c = 0; c < d.Cout / 64; ++c) {
     K9Params p;
-    p.x = a.x; p.w = (const bf16_t*)a.w;
-    p.epi.scale = a.scale; p.epi.shift = a.shift; p.epi.alpha = a.alpha;
-    p.epi.res = (const bf16_t*)a.residual; p.epi.y = (bf16_t*)a.y;
-    p.epi.H = d.H; p.epi.W = d.W; p.epi.Cout = 64; p.epi.out_cs = g.out_cs; p.epi.out_co = d.out_coffset;
+    p.x = a.x; p.w = (const bf16_t*)((const unsigned char*)a.w + (size_t)c * K9_W_BYTES);
+    p.epi.scale = a.scale + 64 * c; p.epi.shift = a.shift + 64 * c;
+    p.epi.alpha = (a.alpha && d.alpha_per_channel) ? a.alpha + 64 * c : a.alpha;
+    p.epi.res = a.residual ? (const bf16_t*)a.residual + 64 * c : nullptr; p.epi.y = (bf16_t*)a.y;
+    p.epi.H = d.H; p.epi.W = d.W; p.epi.Cout = d.Cout; p.epi.out_cs = g.out_cs; p.epi.out_co = d.out_coffset + 64 * c;
     p.epi.mode = C64_PLAIN;
     p.epi.act = d.act; p.epi.act_param = d.act_param; p.epi.alpha_pc = d.alpha_per_channel;
     p.N = d.N; p.H = d.H; p.W = d.W; p.Cin = d.Cin; p.in_cs = g.in_cs;
@@ -225,7 +230,10 @@ int k9c3_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
         if (nb > 0x7fffffffLL) { set_error("k9c3_bf16: grid too large"); return SRMI_EINVAL; }
         hipLaunchKernelGGL((conv_k9c3_kernel<4, 2>), dim3((unsigned)nb), dim3(256), 0, s, p);
     }
-    return hip_check(hipGetLastError(), "conv_k9c3_kernel");
+    int rc = hip_check(hipGetLastError(), "conv_k9c3_kernel");
+    if (rc) return rc;
+    }
+    return SRMI_OK;
 }
 
 }  // namespace srmi

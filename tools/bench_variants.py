@@ -47,6 +47,26 @@ def main():
     run("cfg2 SRCNN 9-3-5 128/64 (reference), 32x1x384x384", SRCNN(), x2, px2, px2 * 171_392.0, args.steps, args.warmup, args.compute)
     run("cfg2 SRCNN 9-1-5 64/32 (BASELINE), 32x1x384x384", SRCNN(k=(9, 1, 5), ch=(64, 32)), x2, px2, px2 * 16_064.0,
         args.steps, args.warmup, args.compute)
+    # cfg5: one 960x540 frame -> 3840x2160 through LR tiles of 270x240 + 8 px halo (8 tiles, here all on one GPU)
+    from srmi.srgan_model import Generator
+    from srmi.tiling import sr_tiled
+    from bench import synthetic_state
+    gen = Generator()
+    gen.load_state_dict(synthetic_state(gen, 0))
+    gen = gen.to("cuda:0").eval().set_compute(args.compute)
+    frame = (torch.rand(1, 3, 540, 960, generator=g) * 2 - 1).to("cuda:0")
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            sr_tiled(gen, frame, tile=(270, 240), halo=8)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out, ntiles = sr_tiled(gen, frame, tile=(270, 240), halo=8)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / args.steps
+    print(json.dumps({"workload": "cfg5 SRResNet x4, 960x540 -> 3840x2160, 8 tiles of 270x240 + 8 px halo, 1 GPU",
+                      "compute": args.compute, "ms_per_frame": round(el * 1e3, 3), "out_mp_per_s": round(8.2944 / el, 1),
+                      "tiles": ntiles}), flush=True)
     x4 = torch.rand(8, 3, 256, 256, generator=g) * 2 - 1
     lr_px = 8 * 256 * 256
     run(f"cfg4 RRDBNet {args.blocks} blocks, 8x3x256x256 -> x4", RRDBNet(num_blocks=args.blocks), x4, lr_px * 16,
