@@ -149,6 +149,15 @@ int srmi_layout_convert(const void* src, void* dst, int32_t N, int32_t C, int32_
                         int32_t src_layout, int32_t src_dtype, int32_t dst_layout, int32_t dst_dtype,
                         void* stream);
 
+/* Image I/O at the edge of the hot path.  uint8 HWC (what PIL/numpy hand over, P/dataset.py:21-22)
+ * -> f32 NCHW in [-1,1], `v / 127.5 - 1` rounded once from f64 exactly as P/dataset.py:40-47 computes it. */
+int srmi_u8hwc_to_f32nchw(const uint8_t* src, float* dst, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);
+
+/* f32 NCHW generator output -> uint8 HWC: [clip to [-1,1] when clip != 0, P/mode.py:360] -> (v+1)/2 -> *255 ->
+ * truncate like numpy's astype(np.uint8) (P/mode.py:397-400); out-of-range values saturate. */
+int srmi_f32nchw_to_u8hwc(const float* src, uint8_t* dst, int32_t N, int32_t H, int32_t W, int32_t C, int32_t clip,
+                          void* stream);
+
 /* ---- losses and metrics (HBM-bound reductions) ------------------------------------------------
  * All results are written to DEVICE memory (no host synchronisation).  `ws` is a caller-owned device
  * workspace of at least SRMI_REDUCE_WS_BYTES bytes, 8-byte aligned; it holds the per-workgroup f64

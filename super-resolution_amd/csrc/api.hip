@@ -49,6 +49,9 @@ int generic_dgrad_launch(const srmi_conv_desc& d, const ConvGeom& g, const float
 int wgrad_launch(const srmi_conv_desc& d, const ConvGeom& g, const float* x, const float* dz, float* dw,
                  hipStream_t s);
 
+int u8_to_f32(const unsigned char* src, float* dst, int N, int H, int W, int C, hipStream_t s);
+int f32_to_u8(const float* src, unsigned char* dst, int N, int H, int W, int C, int clip, hipStream_t s);
+
 static bool is_dtype(int v) { return v == SRMI_F32 || v == SRMI_BF16; }
 static bool is_layout(int v) { return v == SRMI_NHWC || v == SRMI_NCHW; }
 
@@ -254,6 +257,21 @@ int srmi_layout_convert(const void* src, void* dst, int32_t N, int32_t C, int32_
     if ((size_t)N * C * H * W == 0) return SRMI_OK;
     if (!src || !dst) { set_error("layout_convert: NULL buffer"); return SRMI_EINVAL; }
     return layout_convert(src, dst, N, C, H, W, src_layout, src_dtype, dst_layout, dst_dtype, (hipStream_t)stream);
+}
+
+int srmi_u8hwc_to_f32nchw(const uint8_t* src, float* dst, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {
+    if (N < 0 || H < 0 || W < 0 || C <= 0) { set_error("u8hwc_to_f32nchw: bad dims"); return SRMI_EINVAL; }
+    if ((size_t)N * H * W == 0) return SRMI_OK;
+    if (!src || !dst) { set_error("u8hwc_to_f32nchw: NULL buffer"); return SRMI_EINVAL; }
+    return u8_to_f32(src, dst, N, H, W, C, (hipStream_t)stream);
+}
+
+int srmi_f32nchw_to_u8hwc(const float* src, uint8_t* dst, int32_t N, int32_t H, int32_t W, int32_t C, int32_t clip,
+                          void* stream) {
+    if (N < 0 || H < 0 || W < 0 || C <= 0) { set_error("f32nchw_to_u8hwc: bad dims"); return SRMI_EINVAL; }
+    if ((size_t)N * H * W == 0) return SRMI_OK;
+    if (!src || !dst) { set_error("f32nchw_to_u8hwc: NULL buffer"); return SRMI_EINVAL; }
+    return f32_to_u8(src, dst, N, H, W, C, clip, (hipStream_t)stream);
 }
 
 static int check_reduce(const char* what, const void* a, const void* b, const void* out, const void* ws) {

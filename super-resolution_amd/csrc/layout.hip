@@ -55,6 +55,57 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const void* __restric
     }
 }
 
+// uint8 HWC -> f32 NCHW in [-1,1]: v / 127.5 - 1 evaluated in f64 and rounded once, exactly as numpy does it in
+// P/dataset.py:40-47 (`(LR / 127.5) - 1.0` on a float64 array, then .astype(np.float32)).
+__global__ void u8hwc_to_f32nchw_kernel(const unsigned char* __restrict__ src, float* __restrict__ dst, int C, int HW,
+                                        size_t total) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const size_t px = idx % HW;
+        const size_t t = idx / HW;
+        const int c = (int)(t % C);
+        const size_t n = t / C;
+        const double v = (double)src[(n * HW + px) * C + c];
+        dst[idx] = (float)(v / 127.5 - 1.0);
+    }
+}
+
+// f32 NCHW (tanh range) -> uint8 HWC: [clip to [-1,1]] -> (v + 1) / 2 -> * 255 -> truncate, each step one f32
+// rounding as in numpy (P/mode.py:360, :397-400); values outside [0,255] saturate (numpy's cast is undefined there).
+__global__ void f32nchw_to_u8hwc_kernel(const float* __restrict__ src, unsigned char* __restrict__ dst, int C, int HW,
+                                        int clip, size_t total) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        const size_t t = idx / C;
+        const size_t px = t % HW;
+        const size_t n = t / HW;
+        float v = src[(n * C + c) * HW + px];
+        if (clip) v = fminf(fmaxf(v, -1.f), 1.f);
+        v = __fmul_rn(__fdiv_rn(__fadd_rn(v, 1.f), 2.f), 255.f);
+        v = fminf(fmaxf(v, 0.f), 255.f);
+        dst[idx] = (unsigned char)(int)v;     // truncation toward zero
+    }
+}
+
+int u8_to_f32(const unsigned char* src, float* dst, int N, int H, int W, int C, hipStream_t s) {
+    const size_t total = (size_t)N * C * H * W;
+    if (total == 0) return SRMI_OK;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(u8hwc_to_f32nchw_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, C, H * W, total);
+    return hip_check(hipGetLastError(), "u8hwc_to_f32nchw_kernel");
+}
+
+int f32_to_u8(const float* src, unsigned char* dst, int N, int H, int W, int C, int clip, hipStream_t s) {
+    const size_t total = (size_t)N * C * H * W;
+    if (total == 0) return SRMI_OK;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(f32nchw_to_u8hwc_kernel, dim3((unsigned)blocks), dim3(256), 0, s, src, dst, C, H * W, clip, total);
+    return hip_check(hipGetLastError(), "f32nchw_to_u8hwc_kernel");
+}
+
 int layout_convert(const void* src, void* dst, int N, int C, int H, int W, int sl, int sd, int dl, int dd,
                    hipStream_t s) {
     const size_t total = (size_t)N * C * H * W;
