@@ -325,6 +325,7 @@ static int epi_check(const char* what, const srmi_epi_desc* d) {
         set_error("%s: bad descriptor N=%d H=%d W=%d C=%d r=%d act=%d", what, d->N, d->H, d->W, d->C, d->shuffle, d->act);
         return SRMI_EINVAL;
     }
+    if ((long long)d->N * d->H * d->W > 0x7fffffffLL) { set_error("%s: N*H*W exceeds int32", what); return SRMI_EINVAL; }
     return SRMI_OK;
 }
 

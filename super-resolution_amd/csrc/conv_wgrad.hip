@@ -32,8 +32,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
     const int tap = t;
     const int ky = tap / p.kw, kx = tap % p.kw;
     const int split = blockIdx.y * 4 + wave;
-    const int r0 = split * p.rows_per_split;
-    if (r0 >= p.rows) return;  // wave-uniform, no barriers in this kernel
+    const int r0 = min(split * p.rows_per_split, p.rows);   // a wave past the end runs an empty loop (it still joins the barrier)
     const int r1 = min(r0 + p.rows_per_split, p.rows);
     const int co = cot * 32 + i;
     const int ci0 = cit * 32 * NT + i;
@@ -66,6 +65,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
         }
     }
 
+    // the four waves of a workgroup hold partial sums of the SAME tile (consecutive K slices): add them in LDS
+    // so that one wave issues the atomics (4x fewer, and they are what bounds small layers)
+    __shared__ float red[3][NT][16][64];
+    if (wave > 0) {
+#pragma unroll
+        for (int u = 0; u < NT; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[wave - 1][u][e][lane] = acc[u][e];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int u = 0; u < NT; ++u)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[u][e] += red[0][u][e][lane] + red[1][u][e][lane] + red[2][u][e][lane];
+
     // D[row = co][col = ci]: acc[e] holds row (e&3) + 8*(e>>2) + 4*h, column i
     const size_t taps = (size_t)p.kh * p.kw;
 #pragma unroll
@@ -95,10 +110,12 @@ int wgrad_launch(const srmi_conv_desc& d, const ConvGeom& g, const float* x, con
     p.ci_tiles = (d.Cin + 32 * NT - 1) / (32 * NT);
     const long long tiles = (long long)d.kh * d.kw * p.co_tiles * p.ci_tiles;
     if (tiles > 0x7fffffffLL) { set_error("wgrad: too many tiles"); return SRMI_EINVAL; }
-    // split K so that ~4096 waves are in flight, at least 2 output rows per wave
-    long long splits = 4096 / tiles;
+    // split K so that ~2048 waves are in flight (4 per workgroup), at least 64 output pixels per wave
+    long long splits = (2048 / tiles + 3) / 4 * 4;
+    if (splits < 4) splits = 4;
+    const int min_rows = (64 + g.Wo - 1) / g.Wo;
+    if (splits > (p.rows + min_rows - 1) / min_rows) splits = (p.rows + min_rows - 1) / min_rows;
     if (splits < 1) splits = 1;
-    if (splits > (p.rows + 1) / 2) splits = (p.rows + 1) / 2;
     if (splits > 65535 * 4) splits = 65535 * 4;
     p.rows_per_split = (int)((p.rows + splits - 1) / splits);
     splits = (p.rows + p.rows_per_split - 1) / p.rows_per_split;

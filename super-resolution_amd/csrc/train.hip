@@ -22,16 +22,17 @@ struct EpiParams {
 };
 
 // conv-order element (pixel m, channel c) -> (index into the final tensor, final channel)
-__device__ __forceinline__ size_t final_index(const EpiParams& p, long long m, int c, int* cf_out) {
+// (m < 2^31 is checked on the host: 32-bit divisions, the 64-bit ones cost ~20x more)
+__device__ __forceinline__ size_t final_index(const EpiParams& p, int m, int c, int* cf_out) {
     if (p.r == 1) { *cf_out = c; return (size_t)m * p.C + c; }
     const int rr = p.r * p.r;
     int cf, sidx;
     if (p.dcr) { cf = c % p.Cf; sidx = c / p.Cf; } else { cf = c / rr; sidx = c % rr; }
     const int si = sidx / p.r, sj = sidx % p.r;
-    const int ox = (int)(m % p.W);
-    const long long t = m / p.W;
-    const int oy = (int)(t % p.H);
-    const long long n = t / p.H;
+    const int ox = m % p.W;
+    const int t = m / p.W;
+    const int oy = t % p.H;
+    const int n = t / p.H;
     *cf_out = cf;
     return (((size_t)n * p.H * p.r + (size_t)oy * p.r + si) * ((size_t)p.W * p.r) + (size_t)ox * p.r + sj) * p.Cf + cf;
 }
@@ -86,8 +87,8 @@ __global__ void bn_finalize_kernel(const double* __restrict__ acc, long long M, 
 __global__ __launch_bounds__(CH_BLOCK) void epilogue_fwd_kernel(EpiParams p) {
     const size_t total = (size_t)p.M * p.C;
     for (size_t idx = (size_t)blockIdx.x * CH_BLOCK + threadIdx.x; idx < total; idx += (size_t)gridDim.x * CH_BLOCK) {
-        const int c = (int)(idx % p.C);
-        const long long m = (long long)(idx / p.C);
+        const int m = (int)(idx / (unsigned)p.C);
+        const int c = (int)(idx - (size_t)m * p.C);
         float v = p.z[idx];
         if (p.bn) v = (v - p.mean[c]) * p.rstd[c] * p.gamma[c] + p.beta[c];
         int cf;
@@ -109,7 +110,8 @@ __global__ __launch_bounds__(CH_BLOCK) void epilogue_bwd_kernel(EpiParams p) {
     if (c < p.C) {
         float mu = 0.f, rs = 1.f, ga = 1.f, be = 0.f;
         if (p.bn) { mu = p.mean[c]; rs = p.rstd[c]; ga = p.gamma[c]; be = p.beta[c]; }
-        for (long long m = (long long)blockIdx.x * 4 + ty; m < p.M; m += (long long)gridDim.x * 4) {
+        const int M = (int)p.M;
+        for (int m = blockIdx.x * 4 + ty; m < M; m += gridDim.x * 4) {
             const size_t idx = (size_t)m * p.C + c;
             const float zh = (p.z[idx] - mu) * rs;        // = z when !bn
             const float u = p.bn ? zh * ga + be : zh;
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(CH_BLOCK) void bn_bwd_apply_kernel(EpiParams p) {
     const size_t total = (size_t)p.M * p.C;
     const double invM = 1.0 / (double)p.M;
     for (size_t idx = (size_t)blockIdx.x * CH_BLOCK + threadIdx.x; idx < total; idx += (size_t)gridDim.x * CH_BLOCK) {
-        const int c = (int)(idx % p.C);
+        const int c = (int)(idx - (idx / (unsigned)p.C) * p.C);
         const float rs = p.rstd[c];
         const float zh = (p.z[idx] - p.mean[c]) * rs;
         const float m1 = (float)(p.acc[c] * invM), m2 = (float)(p.acc[p.C + c] * invM);
@@ -282,7 +284,8 @@ static unsigned ew_blocks(size_t total) {
 
 static dim3 ch_grid(long long M, int C) {
     long long bx = (M + 63) / 64;  // >= 16 pixels per wave
-    if (bx > 512) bx = 512;
+    const long long cap = 4096 / ((C + 63) / 64);    // ~4096 workgroups in total
+    if (bx > cap) bx = cap;
     if (bx < 1) bx = 1;
     return dim3((unsigned)bx, (unsigned)((C + 63) / 64));
 }
