@@ -138,13 +138,24 @@ __global__ __launch_bounds__(CH_BLOCK) void epilogue_bwd_kernel(EpiParams p) {
     }
     l1[threadIdx.x] = s1; l2[threadIdx.x] = s2; l3[threadIdx.x] = s3;
     __syncthreads();
-    if (ty == 0 && c < p.C) {
+    if (ty == 0) {
+        const bool cv = c < p.C;
         s1 = l1[tx] + l1[tx + 64] + l1[tx + 128] + l1[tx + 192];
         s2 = l2[tx] + l2[tx + 64] + l2[tx + 128] + l2[tx + 192];
-        s3 = l3[tx] + l3[tx + 64] + l3[tx + 128] + l3[tx + 192];
-        atomicAdd(p.acc + c, s1);
-        if (p.bn) atomicAdd(p.acc + p.C + c, s2);
-        if (p.act == SRMI_ACT_PRELU) atomicAdd(p.acc + 2 * p.C + (p.alpha_pc ? cf_thread : 0), s3);
+        s3 = cv ? l3[tx] + l3[tx + 64] + l3[tx + 128] + l3[tx + 192] : 0.0;
+        if (cv) atomicAdd(p.acc + c, s1);
+        if (cv && p.bn) atomicAdd(p.acc + p.C + c, s2);
+        if (p.act == SRMI_ACT_PRELU) {
+            if (p.alpha_pc) {
+                if (cv) atomicAdd(p.acc + 2 * p.C + cf_thread, s3);
+            } else {
+                // one shared slope: every channel adds to the SAME accumulator - reduce the 64 lanes first, or
+                // tens of thousands of same-address atomics serialise (they were 60 % of this kernel's time)
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) s3 += __shfl_down(s3, off);
+                if (tx == 0) atomicAdd(p.acc + 2 * p.C, s3);
+            }
+        }
     }
 }
 
