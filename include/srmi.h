@@ -130,6 +130,14 @@ int srmi_conv2d_pack_weights(const srmi_conv_desc* d, const float* w_oihw, void*
 /* one fused conv (see srmi_conv_desc). */
 int srmi_conv2d_fwd(const srmi_conv_args* a, void* stream);
 
+/* Deterministic variant for the linear-epilogue f32 convs of the training path (scale == NULL, act NONE, no
+ * residual): spatially small, deep layers are split along K to fill the chip; with a workspace of
+ * srmi_conv2d_workspace_bytes(d) bytes the K slices are stored there and added in slice order (same input =>
+ * same bits, which keeps every activation on the same side of its ReLU kink from run to run); srmi_conv2d_fwd
+ * (no workspace) adds them with f32 atomics instead.  bytes = 0: the conv does not split, ws may be NULL. */
+int srmi_conv2d_workspace_bytes(const srmi_conv_desc* d, size_t* bytes);
+int srmi_conv2d_fwd_ws(const srmi_conv_args* a, void* ws, size_t ws_bytes, void* stream);
+
 /* n fused convs enqueued back to back on `stream` from native code (one FFI crossing per forward
  * of `Generator`, P/srgan_model.py:27-39: 37 convs). */
 int srmi_conv2d_fwd_seq(const srmi_conv_args* a, int32_t n, void* stream);

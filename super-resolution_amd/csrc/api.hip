@@ -1,5 +1,6 @@
 // C ABI of libsrmi.so (see include/srmi.h): validation + kernel dispatch.  No allocation, no sync.
 #include <stdarg.h>
+#include <stdlib.h>
 
 #include "common.h"
 
@@ -12,6 +13,16 @@ void set_error(const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
+}
+
+int dbg_flags() {
+    static const int v = [] { const char* e = getenv("SRMI_DBG"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
+int dbg_thin_rows() {
+    static const int v = [] { const char* e = getenv("SRMI_THIN_RB"); return e ? atoi(e) : 0; }();
+    return v;
 }
 
 int hip_check(hipError_t e, const char* what) {
@@ -124,7 +135,7 @@ const char* kernel_label(int k) {
     }
 }
 
-static int conv_fwd_one(const srmi_conv_args* a, hipStream_t s) {
+static int conv_fwd_one(const srmi_conv_args* a, hipStream_t s, void* ws = nullptr, size_t ws_bytes = 0) {
     if (!a) { set_error("conv: NULL args"); return SRMI_EINVAL; }
     ConvGeom g;
     int rc = conv_geom(a->d, &g);
@@ -147,7 +158,7 @@ static int conv_fwd_one(const srmi_conv_args* a, hipStream_t s) {
         case K_THIN_BF16: return thin_launch(*a, g, s);   // rejects a residual (SRMI_EUNSUPPORTED)
         case K_K9C3_BF16: return k9c3_launch(*a, g, s);
         case K_CIN_BF16: return cin_launch(*a, g, s);
-        default: return generic_launch(*a, g, s);
+        default: return generic_launch(*a, g, s, ws, ws_bytes);
     }
 }
 
@@ -201,6 +212,20 @@ int srmi_conv2d_pack_weights(const srmi_conv_desc* d, const float* w_oihw, void*
 }
 
 int srmi_conv2d_fwd(const srmi_conv_args* a, void* stream) { return conv_fwd_one(a, (hipStream_t)stream); }
+
+int srmi_conv2d_workspace_bytes(const srmi_conv_desc* d, size_t* bytes) {
+    if (!d || !bytes) { set_error("workspace_bytes: NULL argument"); return SRMI_EINVAL; }
+    ConvGeom g;
+    int rc = conv_geom(*d, &g);
+    if (rc) return rc;
+    *bytes = select_kernel(*d) == K_GENERIC_F32 ? generic_workspace_bytes(*d, g) : 0;
+    return SRMI_OK;
+}
+
+int srmi_conv2d_fwd_ws(const srmi_conv_args* a, void* ws, size_t ws_bytes, void* stream) {
+    if (ws && ((uintptr_t)ws & 15)) { set_error("conv2d_fwd_ws: workspace must be 16-byte aligned"); return SRMI_EINVAL; }
+    return conv_fwd_one(a, (hipStream_t)stream, ws, ws_bytes);
+}
 
 static bool can_fuse_pair(const srmi_conv_args* a1, const srmi_conv_args* a2) {
     ConvGeom g;

@@ -69,6 +69,11 @@ static inline int pick_tile3x3(int N, int H, int W) {
     return bi;
 }
 
+// Investigation knobs (ablation switches of tools/ablate_*.py), read from the environment ONCE per process:
+// SRMI_DBG = bit mask that skips kernel phases, SRMI_THIN_RB = rows per band of the thin kernel.  0 = product path.
+int dbg_flags();
+int dbg_thin_rows();
+
 // kernel families (dispatch.cpp decides, the .hip files implement)
 enum Kernel { K_GENERIC_F32 = 0, K_C64_BF16 = 1, K_THIN_BF16 = 2, K_K9C3_BF16 = 3, K_CIN_BF16 = 4 };
 const char* kernel_label(int k);
@@ -77,7 +82,8 @@ int select_kernel(const srmi_conv_desc& d);
 // generic f32-MFMA kernel (conv_generic.hip)
 size_t generic_packed_bytes(const srmi_conv_desc& d);
 int generic_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s);
-int generic_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s);
+int generic_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s, void* ws = nullptr, size_t ws_bytes = 0);
+size_t generic_workspace_bytes(const srmi_conv_desc& d, const ConvGeom& g);
 
 // bf16 MFMA kernel for 3x3 / Cin=64 / Cout%64==0 (conv_c64_bf16.hip)
 bool c64_supported(const srmi_conv_desc& d);

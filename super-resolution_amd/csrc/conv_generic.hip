@@ -26,6 +26,8 @@ struct GenericParams {
     int Cin_pad, Cout_pad, M;
     hipStream_t stream;
     int ksplit;      // > 1: grid.z slices of K, partial sums added to a pre-zeroed f32 y (no activation / residual)
+    float* partial;  // ksplit > 1: when set, slice z STORES its partial tile at partial + z * partial_stride (same
+    size_t partial_stride;  // indexing as y) and generic_splitk_reduce_kernel adds the slices in index order: deterministic
     int transposed;  // dgrad: gather dz at (o + pad - k) / stride where divisible
 };
 
@@ -147,7 +149,11 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(GenericParams p) {
                 oidx = px * p.out_cs + p.out_co + c;
                 ridx = px * p.res_cs + c;
             }
-            if (p.ksplit > 1) { unsafeAtomicAdd((float*)p.y + oidx, val); continue; }
+            if (p.ksplit > 1) {
+                if (p.partial) p.partial[(size_t)blockIdx.z * p.partial_stride + oidx] = val;
+                else unsafeAtomicAdd((float*)p.y + oidx, val);
+                continue;
+            }
             if (p.res) val += p.res_bf16 ? bf2f(((const bf16_t*)p.res)[ridx]) : ((const float*)p.res)[ridx];
             if (p.out_bf16) ((bf16_t*)p.y)[oidx] = f2bf(val);
             else ((float*)p.y)[oidx] = val;
@@ -222,10 +228,62 @@ int generic_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, h
 
 static int generic_run(const struct GenericParams& p);
 
-int generic_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
+// y[i] = partial[0][i] + partial[1][i] + ... in slice order (slice 0 carries the shift)
+__global__ void generic_splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ y, size_t n,
+                                             int ksplit) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        float v = partial[i];
+        for (int z = 1; z < ksplit; ++z) v += partial[(size_t)z * n + i];
+        y[i] = v;
+    }
+}
+
+// number of K slices generic_run will use for these parameters (1 = no split)
+static int generic_ksplit(const GenericParams& p) {
+    const unsigned gy = p.Cout > 32 ? (unsigned)((p.Cout + 63) / 64) : 1u;
+    const long long waves = (long long)((p.M + 31) / 32) * gy;
+    const int KC = p.kh * p.kw * (p.Cin_pad / 8);
+    if (p.scale || p.act != SRMI_ACT_NONE || p.res || p.out_bf16 || p.r != 1 || waves >= 2048 || KC < 16) return 1;
+    if (!p.out_nchw && p.out_cs != p.Cf) return 1;   // channel-slice outputs cannot be zero-filled / reduced densely
+    long long ks = (4096 + waves - 1) / waves;
+    if (ks > KC / 8) ks = KC / 8;                    // at least 8 chunks (64 channels of one tap) per slice
+    if (ks > 256) ks = 256;
+    return ks > 1 ? (int)ks : 1;
+}
+
+static void generic_fill(GenericParams& p, const srmi_conv_args& a, const ConvGeom& g);
+
+// bytes of workspace that make the forward conv's split-K deterministic (0: it does not split)
+size_t generic_workspace_bytes(const srmi_conv_desc& d, const ConvGeom& g) {
+    srmi_conv_args a;
+    memset(&a, 0, sizeof(a));
+    a.d = d;
+    GenericParams p;
+    generic_fill(p, a, g);
+    const long long M = (long long)d.N * g.Ho * g.Wo;
+    if (M <= 0 || M > 0x7fffffffLL) return 0;
+    p.M = (int)M;
+    const int ks = generic_ksplit(p);
+    return ks > 1 ? (size_t)ks * d.N * g.Cf * g.Hf * g.Wf * sizeof(float) : 0;
+}
+
+int generic_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s, void* ws, size_t ws_bytes) {
     const srmi_conv_desc& d = a.d;
     GenericParams p;
+    generic_fill(p, a, g);
     p.stream = s;
+    p.partial = (float*)ws;
+    p.partial_stride = ws ? ws_bytes / sizeof(float) : 0;     // capacity in elements until generic_run fixes the stride
+    const long long M = (long long)d.N * g.Ho * g.Wo;
+    if (M > 0x7fffffffLL) { set_error("generic conv: N*Ho*Wo = %lld exceeds int32", M); return SRMI_EINVAL; }
+    p.M = (int)M;
+    if (p.M == 0) return SRMI_OK;
+    return generic_run(p);
+}
+
+static void generic_fill(GenericParams& p, const srmi_conv_args& a, const ConvGeom& g) {
+    const srmi_conv_desc& d = a.d;
+    memset(&p, 0, sizeof(p));
     p.x = a.x; p.w = (const float*)a.w; p.scale = a.scale; p.shift = a.shift; p.alpha = a.alpha;
     p.res = a.residual; p.y = a.y;
     p.N = d.N; p.H = d.H; p.W = d.W; p.Cin = d.Cin; p.Cout = d.Cout; p.kh = d.kh; p.kw = d.kw;
@@ -240,13 +298,8 @@ int generic_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     p.act = d.act; p.act_param = d.act_param; p.alpha_pc = d.alpha_per_channel;
     p.r = d.shuffle; p.dcr = d.shuffle_order == SRMI_SHUFFLE_DCR;
     p.Cin_pad = round_up(d.Cin, 8); p.Cout_pad = round_up(d.Cout, 32);
-    const long long M = (long long)d.N * g.Ho * g.Wo;
-    if (M > 0x7fffffffLL) { set_error("generic conv: N*Ho*Wo = %lld exceeds int32", M); return SRMI_EINVAL; }
-    p.M = (int)M;
     p.transposed = 0;
     p.ksplit = 1;
-    if (p.M == 0) return SRMI_OK;
-    return generic_run(p);
 }
 
 static int generic_run(const GenericParams& p0) {
@@ -257,21 +310,15 @@ static int generic_run(const GenericParams& p0) {
     // Split K when the pixel x channel tiling alone cannot fill 256 CUs (deep, spatially small layers: the
     // discriminator tail, VGG conv4/conv5, Linear layers, their dgrads).  Needs a linear epilogue with unit
     // scale and a dense f32 output, which is what the training path asks for; partials meet in f32 atomics.
-    p.ksplit = 1;
-    const long long waves = (long long)((p.M + 31) / 32) * gy;
-    const int KC = p.kh * p.kw * (p.Cin_pad / 8);
-    if (!p.scale && p.act == SRMI_ACT_NONE && !p.res && !p.out_bf16 && p.r == 1 && waves < 2048 && KC >= 16) {
-        long long ks = (4096 + waves - 1) / waves;
-        if (ks > KC / 8) ks = KC / 8;              // at least 8 chunks (64 channels of one tap) per slice
-        if (ks > 256) ks = 256;
-        if (ks > 1) {
-            p.ksplit = (int)ks;
-            const size_t bytes = (size_t)p.N * p.Cf * p.Hf * p.Wf * sizeof(float);
-            if (!p.out_nchw && p.out_cs != p.Cf) { p.ksplit = 1; }   // channel-slice outputs cannot be zero-filled
-            else {
-                int rc = hip_check(hipMemsetAsync(p.y, 0, bytes, s), "split-K memset");
-                if (rc) return rc;
-            }
+    p.ksplit = generic_ksplit(p);
+    const size_t out_elems = (size_t)p.N * p.Cf * p.Hf * p.Wf;
+    if (p.ksplit > 1) {
+        if (p.partial && p.partial_stride >= out_elems * (size_t)p.ksplit) {
+            p.partial_stride = out_elems;            // deterministic: slices stored, then reduced in order
+        } else {
+            p.partial = nullptr;                     // no (or too small a) workspace: f32 atomics into a zeroed y
+            int rc = hip_check(hipMemsetAsync(p.y, 0, out_elems * sizeof(float), s), "split-K memset");
+            if (rc) return rc;
         }
     }
     dim3 grid(gx, gy, (unsigned)p.ksplit);
@@ -280,7 +327,13 @@ static int generic_run(const GenericParams& p0) {
     } else {
         hipLaunchKernelGGL(conv_generic_kernel<1>, grid, dim3(256), 0, s, p);
     }
-    return hip_check(hipGetLastError(), "conv_generic_kernel");
+    int rc = hip_check(hipGetLastError(), "conv_generic_kernel");
+    if (rc || p.ksplit <= 1 || !p.partial) return rc;
+    size_t blocks = (out_elems + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(generic_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p.partial, (float*)p.y,
+                       out_elems, p.ksplit);
+    return hip_check(hipGetLastError(), "generic_splitk_reduce_kernel");
 }
 
 // dx[N,H,W,Cin] = conv_transpose(dz[N,Ho,Wo,Cout], w): the forward descriptor `d` describes the conv whose

@@ -296,8 +296,8 @@ int thin_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     int rb = (int)((d.H + nbands - 1) / nbands);
     if (rb < 8) rb = 8;
     if (rb > d.H) rb = d.H;
-    { const char* e = getenv("SRMI_THIN_RB"); if (e && atoi(e) > 0) rb = atoi(e) > d.H ? d.H : atoi(e); }
-    { const char* e = getenv("SRMI_DBG"); p.dbg = e ? atoi(e) : 0; }
+    if (dbg_thin_rows() > 0) rb = dbg_thin_rows() > d.H ? d.H : dbg_thin_rows();
+    p.dbg = dbg_flags();
     p.band_rows = rb;
     p.bands = (d.H + rb - 1) / rb;
     const long long nb = (long long)d.N * p.strips * p.bands;

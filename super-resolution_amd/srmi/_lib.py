@@ -75,6 +75,8 @@ SYMBOLS = {
     "srmi_conv2d_packed_weight_bytes": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_size_t)]),
     "srmi_conv2d_pack_weights": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_void_p, C.c_void_p]),
     "srmi_conv2d_fwd": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "srmi_conv2d_workspace_bytes": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_size_t)]),
+    "srmi_conv2d_fwd_ws": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p, C.c_size_t, C.c_void_p]),
     "srmi_conv2d_fwd_seq": (C.c_int, [C.POINTER(ConvArgs), C.c_int32, C.c_void_p]),
     "srmi_conv2d_can_fuse": (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs)]),
     "srmi_resblock_fwd": (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), C.c_void_p]),

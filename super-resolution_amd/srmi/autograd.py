@@ -101,7 +101,13 @@ class FusedConvFn(torch.autograd.Function):
         wp = Fn.pack_weights(desc, w)
         shift = bias.detach().contiguous() if bias is not None else None
         z = _empty_cl((N, Cout, Ho, Wo), dev)
-        Fn.conv2d_fused(desc, x, wp, None, shift, out=z)       # scale NULL = 1: lets the kernel split K on small maps
+        # scale NULL = 1: lets the kernel split K on small maps; the workspace makes that split deterministic
+        a = L.ConvArgs()
+        Fn.fill_args(a, desc, x, wp, None, shift, None, None, z)
+        nws = C.c_size_t(0)
+        L.check(lib.srmi_conv2d_workspace_bytes(C.byref(desc), C.byref(nws)))
+        wsk = torch.empty(nws.value, dtype=torch.uint8, device=dev) if nws.value else None
+        L.check(lib.srmi_conv2d_fwd_ws(C.byref(a), _ptr(wsk), nws.value, st))
 
         bn = cfg.bn
         mean = rstd = None

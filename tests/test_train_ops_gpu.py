@@ -186,3 +186,25 @@ def test_eval_bn_under_autograd_is_rejected():
     bn = nn.BatchNorm2d(4).to(DEV).eval()
     with pytest.raises(NotImplementedError):
         AG.fused_conv(torch.zeros(1, 4, 4, 4, device=DEV), c2d, bn, None)
+
+
+def test_training_forward_is_bit_deterministic():
+    """Deep, spatially small layers split K; with the workspace of srmi_conv2d_workspace_bytes the slices are
+    added in a fixed order, so the train-mode forward gives the same bits every time (which keeps activations on
+    the same side of their ReLU kinks from run to run)."""
+    import ctypes as C
+    from srmi import functional as Fn
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(8, 512, 6, 6, generator=g).to(DEV)
+    c2d = nn.Conv2d(512, 512, 3, padding=1).to(DEV)
+    desc = Fn.make_desc(8, 6, 6, 512, 512, 3)
+    n = C.c_size_t(0)
+    L.check(L.load().srmi_conv2d_workspace_bytes(C.byref(desc), C.byref(n)))
+    assert n.value > 0 and n.value % (8 * 6 * 6 * 512 * 4) == 0          # this shape does split
+    ys = [AG.fused_conv(x, c2d, None, nn.LeakyReLU()).clone() for _ in range(4)]
+    assert all(torch.equal(ys[0], y) for y in ys[1:])
+    ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x.cpu(), c2d.weight.cpu(), c2d.bias.cpu(), padding=1))
+    _close(ys[0], ref, 1e-4, "split-K forward")
+    big = Fn.make_desc(16, 96, 96, 64, 64, 3)                             # plenty of pixels: no split, no workspace
+    L.check(L.load().srmi_conv2d_workspace_bytes(C.byref(big), C.byref(n)))
+    assert n.value == 0
