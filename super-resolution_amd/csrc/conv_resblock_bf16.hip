@@ -36,18 +36,21 @@ struct ResBlockParams {
 constexpr int RB_SLOTS = 4;
 constexpr int RB_STEP_BYTES = 4096;   // one K-step: 4 channel tiles x 64 lanes x 16 B
 
-template <int TH, int TWT>
-__global__ __launch_bounds__(256, 1) void resblock_c64_kernel(ResBlockParams p) {
+// NW = waves per workgroup: 4 (one per SIMD, 512 registers each) or 8 (two per SIMD, 256 each: the second wave
+// of a SIMD fills the first one's LDS / barrier / VALU-epilogue bubbles; same tile, same LDS, half the pixel
+// tiles per wave).
+template <int TH, int TWT, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void resblock_c64_kernel(ResBlockParams p) {
+    constexpr int NTH = NW * 64;
     constexpr int TW = TWT * 16;
     constexpr int XR = TH + 4, XC = TW + 4;          // x halo tile
     constexpr int TR = TH + 2, TC = TW + 2;          // T region
     constexpr int ROWP = (XC + 15) / 16 * 16;        // LDS row pitch in pixels (multiple of 16)
     constexpr int IN_BYTES = XR * ROWP * 128;
     constexpr int NT1 = (TR * TC + 15) / 16;         // flattened 16-pixel tiles of the T region
-    constexpr int PT1 = (NT1 + 3) / 4;
+    constexpr int PT1 = (NT1 + NW - 1) / NW;
     constexpr int NPT2 = TH * TWT;
-    static_assert(NPT2 % 4 == 0, "pixel tiles must split evenly over 4 waves");
-    constexpr int PT2 = NPT2 / 4;
+    constexpr int PT2 = (NPT2 + NW - 1) / NW;          // waves past the end recompute the last tile and store nothing
     __shared__ __attribute__((aligned(16))) unsigned char lds[IN_BYTES + RB_SLOTS * RB_STEP_BYTES + 2 * 768];
     unsigned char* const wring = lds + IN_BYTES;
     float* const par = (float*)(lds + IN_BYTES + RB_SLOTS * RB_STEP_BYTES);
@@ -74,6 +77,7 @@ __global__ __launch_bounds__(256, 1) void resblock_c64_kernel(ResBlockParams p) 
         const unsigned dst = __builtin_amdgcn_readfirstlane(
             wring_lds + (unsigned)((g & (RB_SLOTS - 1)) * RB_STEP_BYTES + wave * 1024));
         unsigned keep;
+        if (wave < 4)      // a K-step is 4 KiB = four 1-KiB DMA instructions: waves 4..7 (NW = 8) issue none
         asm volatile(
             "s_mov_b32 %0, m0\n\t"
             "s_mov_b32 m0, %2\n\t"
@@ -94,12 +98,12 @@ __global__ __launch_bounds__(256, 1) void resblock_c64_kernel(ResBlockParams p) 
     // ---- stage the x halo tile (2-pixel ring) ----------------------------------------------------
     if (!(p.dbg & 1)) {
         constexpr int NCH = XR * XC * 8;
-        constexpr int NIT = (NCH + 255) / 256;
+        constexpr int NIT = (NCH + NTH - 1) / NTH;
         const bf16_t* xin = p.x + (size_t)n * p.H * p.W * p.in_cs;
         u32x4 v[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int idx = min(tid + it * 256, NCH - 1);
+            const int idx = min(tid + it * NTH, NCH - 1);
             const int pp = idx >> 3, ch = idx & 7;
             const int row = pp / XC, col = pp - row * XC;
             const int gy = min(max(y0 - 2 + row, 0), p.H - 1), gx = min(max(x0 - 2 + col, 0), p.W - 1);
@@ -107,7 +111,7 @@ __global__ __launch_bounds__(256, 1) void resblock_c64_kernel(ResBlockParams p) 
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int idx = tid + it * 256;
+            const int idx = tid + it * NTH;
             const int pp = idx >> 3, ch = idx & 7;
             const int row = pp / XC, col = pp - row * XC;
             const int gy = y0 - 2 + row, gx = x0 - 2 + col;
@@ -239,7 +243,7 @@ __global__ __launch_bounds__(256, 1) void resblock_c64_kernel(ResBlockParams p) 
         int boff2[PT2][3];
 #pragma unroll
         for (int k = 0; k < PT2; ++k) {
-            const int t = wave * PT2 + k;
+            const int t = min(wave * PT2 + k, NPT2 - 1);
             prow[k] = t / TWT;
             pcol[k] = (t - prow[k] * TWT) * 16;
 #pragma unroll
@@ -247,6 +251,7 @@ __global__ __launch_bounds__(256, 1) void resblock_c64_kernel(ResBlockParams p) 
                 const int P = prow[k] * ROWP + pcol[k] + pl + dx;
                 boff2[k][dx] = P * 128 + ((q ^ ((P >> 1) & 7)) << 4);
             }
+            if (wave * PT2 + k >= NPT2) prow[k] = 1 << 20;     // padding tile: the epilogue's bounds check drops it
         }
         f32x4 acc2[PT2][4];
 #pragma unroll
@@ -323,12 +328,13 @@ int resblock_launch(const srmi_conv_args& a1, const srmi_conv_args& a2, hipStrea
         p.tiles_x = (d1.W + 95) / 96; p.tiles_y = (d1.H + 5) / 6;
         const long long nb = (long long)d1.N * p.tiles_x * p.tiles_y;
         if (nb > 0x7fffffffLL) { set_error("resblock_bf16: grid too large"); return SRMI_EINVAL; }
-        hipLaunchKernelGGL((resblock_c64_kernel<6, 6>), dim3((unsigned)nb), dim3(256), 0, s, p);
+        if (p.dbg & 128) hipLaunchKernelGGL((resblock_c64_kernel<6, 6, 4>), dim3((unsigned)nb), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((resblock_c64_kernel<6, 6, 8>), dim3((unsigned)nb), dim3(512), 0, s, p);
     } else {
         p.tiles_x = (d1.W + 31) / 32; p.tiles_y = (d1.H + 3) / 4;
         const long long nb = (long long)d1.N * p.tiles_x * p.tiles_y;
         if (nb > 0x7fffffffLL) { set_error("resblock_bf16: grid too large"); return SRMI_EINVAL; }
-        hipLaunchKernelGGL((resblock_c64_kernel<4, 2>), dim3((unsigned)nb), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((resblock_c64_kernel<4, 2, 4>), dim3((unsigned)nb), dim3(256), 0, s, p);
     }
     return hip_check(hipGetLastError(), "resblock_c64_kernel");
 }
