@@ -40,12 +40,16 @@ struct C64Params {
 constexpr int C64_WRING = 4;          // weight ring slots (one 3x3 tap = 8 KiB of A fragments per slot)
 constexpr int C64_TAP_BYTES = 8192;   // 2 k-steps x 4 channel tiles x 64 lanes x 16 B
 
-template <int TH, int TWT>
-__global__ __launch_bounds__(256, 1) void conv_c64_kernel(C64Params p) {
+// NW = waves per workgroup: 4 (one per SIMD, 512 registers each) or 8 (two per SIMD, 256 each: the second wave of a
+// SIMD fills the first one's LDS / barrier / epilogue bubbles; same tile and LDS, half the pixel tiles per wave).
+template <int TH, int TWT, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void conv_c64_kernel(C64Params p) {
+    constexpr int NTH = NW * 64;
     constexpr int TW = TWT * 16;
     constexpr int NPT = TH * TWT;
-    static_assert(NPT % 4 == 0, "pixel tiles must split evenly over 4 waves");
-    constexpr int PT = NPT / 4;
+    constexpr int PT = (NPT + NW - 1) / NW;            // waves past the end recompute the last tile and store nothing
+    constexpr int WAVE_BYTES = C64_TAP_BYTES / NW;     // each wave moves 1/NW of every tap
+    constexpr int NDMA = WAVE_BYTES / 1024;            // LDS-DMA instructions per wave and tap (2 or 1)
     constexpr int ROWP = (TW + 2 + 15) / 16 * 16;  // LDS row pitch in pixels (multiple of 16: swizzle independent of dy)
     constexpr int IN_BYTES = (TH + 2) * ROWP * 128;
     // ONE shared array (input tile | weight ring): a second __shared__ object next to an LDS-DMA
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(256, 1) void conv_c64_kernel(C64Params p) {
     // ---- weight stream: packed A fragments, one tap (8 KiB) per ring slot, moved by LDS-DMA ------
     // wave w copies KiB 2w and 2w+1 of each tap; the LDS image is lane-linear (= fragment order).
     const int ntap = p.nchunk * 9;
-    const unsigned char* wsrc = (const unsigned char*)p.w + (wave * 2) * 1024 + lane * 16;
+    const unsigned char* wsrc = (const unsigned char*)p.w + wave * WAVE_BYTES + lane * 16;
     // The DMA is issued from inline asm on purpose: hipcc tracks a builtin LDS-DMA as an LDS write that
     // may alias every later ds_read of the same array and drains vmcnt(0) in front of it, which would
     // serialise the ring.  Here the hand-off is ordered by hand (counted vmcnt + s_barrier below).
@@ -80,20 +84,32 @@ __global__ __launch_bounds__(256, 1) void conv_c64_kernel(C64Params p) {
     auto issue_tap = [&](int g) {
         const unsigned char* src = wsrc + (size_t)g * C64_TAP_BYTES;
         const unsigned dst = __builtin_amdgcn_readfirstlane(
-            wring_lds + (unsigned)((g & (C64_WRING - 1)) * C64_TAP_BYTES + (wave * 2) * 1024));
+            wring_lds + (unsigned)((g & (C64_WRING - 1)) * C64_TAP_BYTES + wave * WAVE_BYTES));
         unsigned keep;
-        asm volatile(
-            "s_mov_b32 %0, m0\n\t"
-            "s_mov_b32 m0, %3\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %1, off\n\t"
-            "s_add_u32 m0, m0, 0x400\n\t"
-            "s_nop 0\n\t"
-            "global_load_lds_dwordx4 %2, off\n\t"
-            "s_mov_b32 m0, %0"
-            : "=&s"(keep)
-            : "v"(src), "v"(src + 1024), "s"(dst)
-            : "memory", "scc");
+        if constexpr (NDMA == 2) {
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %3\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %1, off\n\t"
+                "s_add_u32 m0, m0, 0x400\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %2, off\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(src), "v"(src + 1024), "s"(dst)
+                : "memory", "scc");
+        } else {
+            asm volatile(
+                "s_mov_b32 %0, m0\n\t"
+                "s_mov_b32 m0, %2\n\t"
+                "s_nop 0\n\t"
+                "global_load_lds_dwordx4 %1, off\n\t"
+                "s_mov_b32 m0, %0"
+                : "=&s"(keep)
+                : "v"(src), "s"(dst)
+                : "memory");
+        }
     };
     issue_tap(0);
     if (ntap > 1) issue_tap(1);
@@ -107,12 +123,12 @@ __global__ __launch_bounds__(256, 1) void conv_c64_kernel(C64Params p) {
     // one HBM/L2 round trip for the whole tile instead of one per 16-B chunk.
     {
         constexpr int NCH = (TH + 2) * (TW + 2) * 8;  // 16-B chunks
-        constexpr int NIT = (NCH + 255) / 256;
+        constexpr int NIT = (NCH + NTH - 1) / NTH;
         const bf16_t* xin = p.x + (size_t)n * p.H * p.W * p.in_cs;
         u32x4 v[NIT];
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int idx = min(tid + it * 256, NCH - 1);
+            const int idx = min(tid + it * NTH, NCH - 1);
             const int pp = idx >> 3, ch = idx & 7;
             const int row = pp / (TW + 2), col = pp - row * (TW + 2);
             const int gy = min(max(y0 - 1 + row, 0), p.H - 1), gx = min(max(x0 - 1 + col, 0), p.W - 1);
@@ -120,7 +136,7 @@ __global__ __launch_bounds__(256, 1) void conv_c64_kernel(C64Params p) {
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int idx = tid + it * 256;
+            const int idx = tid + it * NTH;
             const int pp = idx >> 3, ch = idx & 7;
             const int row = pp / (TW + 2), col = pp - row * (TW + 2);
             const int gy = y0 - 1 + row, gx = x0 - 1 + col;
@@ -136,7 +152,7 @@ __global__ __launch_bounds__(256, 1) void conv_c64_kernel(C64Params p) {
     int prow[PT], pcol[PT];
 #pragma unroll
     for (int k = 0; k < PT; ++k) {
-        const int t = wave * PT + k;
+        const int t = min(wave * PT + k, NPT - 1);
         prow[k] = t / TWT;
         pcol[k] = (t - prow[k] * TWT) * 16;
     }
@@ -156,6 +172,9 @@ __global__ __launch_bounds__(256, 1) void conv_c64_kernel(C64Params p) {
             const int P = prow[k] * ROWP + pcol[k] + pl + dx;
             boff[k][dx] = P * 128 + ((q ^ ((P >> 1) & 7)) << 4);
         }
+#pragma unroll
+    for (int k = 0; k < PT; ++k)
+        if (wave * PT + k >= NPT) prow[k] = 1 << 20;   // padding tile: the epilogue's bounds check drops it
 
     for (int s = 0; s < p.nchunk; ++s) {
         f32x4 acc[PT][4];
@@ -185,7 +204,7 @@ __global__ __launch_bounds__(256, 1) void conv_c64_kernel(C64Params p) {
             if (half == 1) {
                 // tap g+1 landed: own copies by counted vmcnt (tap g+2 stays in flight), the other waves'
                 // by the barrier, which also retires every wave's reads of tap g-1 -> its slot is free.
-                if (g + 2 < ntap) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+                if (g + 2 < ntap) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 if (g + 3 < ntap) issue_tap(g + 3);
@@ -301,9 +320,12 @@ int c64_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     p.tiles_x = (d.W + tw[tile] - 1) / tw[tile]; p.tiles_y = (d.H + th[tile] - 1) / th[tile];
     const long long nb = (long long)d.N * p.tiles_x * p.tiles_y;
     if (nb > 0x7fffffffLL) { set_error("c64_bf16: grid too large"); return SRMI_EINVAL; }
-    if (tile == 0) hipLaunchKernelGGL((conv_c64_kernel<6, 6>), dim3((unsigned)nb), dim3(256), 0, s, p);
-    else if (tile == 1) hipLaunchKernelGGL((conv_c64_kernel<8, 4>), dim3((unsigned)nb), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((conv_c64_kernel<4, 2>), dim3((unsigned)nb), dim3(256), 0, s, p);
+    const bool w4 = (p.dbg & 256) != 0;    // ablation: the 4-wave variants
+    if (tile == 0 && w4) hipLaunchKernelGGL((conv_c64_kernel<6, 6, 4>), dim3((unsigned)nb), dim3(256), 0, s, p);
+    else if (tile == 0) hipLaunchKernelGGL((conv_c64_kernel<6, 6, 8>), dim3((unsigned)nb), dim3(512), 0, s, p);
+    else if (tile == 1 && w4) hipLaunchKernelGGL((conv_c64_kernel<8, 4, 4>), dim3((unsigned)nb), dim3(256), 0, s, p);
+    else if (tile == 1) hipLaunchKernelGGL((conv_c64_kernel<8, 4, 8>), dim3((unsigned)nb), dim3(512), 0, s, p);
+    else hipLaunchKernelGGL((conv_c64_kernel<4, 2, 4>), dim3((unsigned)nb), dim3(256), 0, s, p);
     return hip_check(hipGetLastError(), "conv_c64_kernel");
 }
 
