@@ -32,17 +32,18 @@ struct CinParams {
 
 constexpr int CIN_WRING = 4;
 
-template <int TH, int TWT, int NCT>
-__global__ __launch_bounds__(256, 1) void conv_cin_kernel(CinParams p) {
+template <int TH, int TWT, int NCT, int NW>
+__global__ __launch_bounds__(NW * 64, 1) void conv_cin_kernel(CinParams p) {
+    constexpr int NTH = NW * 64;
     constexpr int TW = TWT * 16;
     constexpr int NPT = TH * TWT;
-    static_assert(NPT % 4 == 0, "pixel tiles must split evenly over 4 waves");
-    constexpr int PT = NPT / 4;
+    constexpr int PT = (NPT + NW - 1) / NW;            // waves past the end recompute the last tile and store nothing
     constexpr int ROWP = (TW + 2 + 15) / 16 * 16;
     constexpr int IN_BYTES = (TH + 2) * ROWP * 128;
     constexpr int TAP_BYTES = 2 * NCT * 1024;          // 2 k-steps x NCT channel tiles x 64 lanes x 16 B
-    constexpr int WAVE_BYTES = TAP_BYTES / 4;          // each wave moves a quarter of every tap
-    constexpr int NDMA = WAVE_BYTES / 1024;            // LDS-DMA instructions per wave and tap (2 or 1)
+    constexpr int NDW = TAP_BYTES / 1024 < NW ? TAP_BYTES / 1024 : NW;   // waves that move weights (1 KiB DMA granularity)
+    constexpr int WAVE_BYTES = TAP_BYTES / NDW;
+    constexpr int NDMA = WAVE_BYTES / 1024;            // LDS-DMA instructions per moving wave and tap (2 or 1)
     constexpr int CG = NCT * 16;                       // output channels of this workgroup
     __shared__ __attribute__((aligned(16))) unsigned char lds[IN_BYTES + CIN_WRING * TAP_BYTES + 3 * 64 * 4];
     unsigned char* const wring = lds + IN_BYTES;
@@ -71,6 +72,7 @@ __global__ __launch_bounds__(256, 1) void conv_cin_kernel(CinParams p) {
         const unsigned dst = __builtin_amdgcn_readfirstlane(
             wring_lds + (unsigned)((g & (CIN_WRING - 1)) * TAP_BYTES + wave * WAVE_BYTES));
         unsigned keep;
+        if (wave >= NDW) return;
         if constexpr (NDMA == 2) {
             asm volatile(
                 "s_mov_b32 %0, m0\n\t"
@@ -115,7 +117,7 @@ __global__ __launch_bounds__(256, 1) void conv_cin_kernel(CinParams p) {
     int prow[PT], pcol[PT];
 #pragma unroll
     for (int k = 0; k < PT; ++k) {
-        const int t = wave * PT + k;
+        const int t = min(wave * PT + k, NPT - 1);
         prow[k] = t / TWT;
         pcol[k] = (t - prow[k] * TWT) * 16;
     }
@@ -140,12 +142,14 @@ __global__ __launch_bounds__(256, 1) void conv_cin_kernel(CinParams p) {
         if (kc > 0) __builtin_amdgcn_s_barrier();      // every wave has consumed the previous chunk's tile
         {
             constexpr int NCH = (TH + 2) * (TW + 2) * 8;
-            constexpr int NIT = (NCH + 255) / 256;
+            constexpr int NIT = (NCH + NTH - 1) / NTH;
             const int cvalid = min(p.Cin - kc * 64, 64) >> 3;      // 16-B channel chunks that exist (8 or 4)
+            int tid_o;       // opaque copy of tid: keeps hipcc from hoisting the per-load addresses out of the chunk
+            asm volatile("v_mov_b32 %0, %1" : "=v"(tid_o) : "v"(tid));   // loop (they would be spilled across the K loop)
             u32x4 v[NIT];
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int idx = min(tid + it * 256, NCH - 1);
+                const int idx = min(tid_o + it * NTH, NCH - 1);
                 const int pp = idx >> 3, ch = idx & 7;
                 const int row = pp / (TW + 2), col = pp - row * (TW + 2);
                 const int gy = min(max(y0 - 1 + row, 0), p.H - 1), gx = min(max(x0 - 1 + col, 0), p.W - 1);
@@ -154,7 +158,7 @@ __global__ __launch_bounds__(256, 1) void conv_cin_kernel(CinParams p) {
             }
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int idx = tid + it * 256;
+                const int idx = tid_o + it * NTH;
                 const int pp = idx >> 3, ch = idx & 7;
                 const int row = pp / (TW + 2), col = pp - row * (TW + 2);
                 const int gy = y0 - 1 + row, gx = x0 - 1 + col;
@@ -214,33 +218,28 @@ __global__ __launch_bounds__(256, 1) void conv_cin_kernel(CinParams p) {
     // channel map (cin_row_to_cl): lane (pl, q) holds, of channel tile t, rows 4q..4q+3; with NCT = 4 these are
     // channels 8q..8q+7 and 32+8q..32+8q+7 of the group (two 16-B stores), with NCT = 2 channels 8q..8q+7 (one).
     constexpr int NH = NCT / 2;                        // 8-channel runs per lane
-    float sc[8 * NH], sh[8 * NH], sl[8 * NH];
-#pragma unroll
-    for (int hi = 0; hi < NH; ++hi)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = 32 * hi + 8 * q + e;
-            sc[8 * hi + e] = par[c];
-            sh[8 * hi + e] = par[64 + c];
-            sl[8 * hi + e] = par[128 + c];
-        }
     int opaque0;
     asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));
 #pragma unroll
     for (int k = 0; k < PT; ++k) {
         const int oy = y0 + prow[k], ox = x0 + pcol[k] + pl + opaque0;
-        if (!(oy < p.H && ox < p.W)) continue;
+        if (!(oy < p.H && ox < p.W) || wave * PT + k >= NPT) continue;
         const size_t pix = ((size_t)n * p.H + oy) * p.W + ox;
 #pragma unroll
         for (int hi = 0; hi < NH; ++hi) {
+            // parameters of this lane's 8 channels, re-read from LDS per run (keeps the epilogue under the
+            // 256-register budget of the 8-wave variants)
+            const float* pc = par + 32 * hi + 8 * q;
+            const f32x4 sc0 = *(const f32x4*)pc, sc1 = *(const f32x4*)(pc + 4);
+            const f32x4 sh0 = *(const f32x4*)(pc + 64), sh1 = *(const f32x4*)(pc + 68);
+            const f32x4 sl0 = *(const f32x4*)(pc + 128), sl1 = *(const f32x4*)(pc + 132);
             float v[8];
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    const int c = 8 * hi + 4 * tt + e;
-                    const float z = acc[k][2 * hi + tt][e] * sc[c] + sh[c];
-                    v[4 * tt + e] = z >= 0.f ? z : z * sl[c];
+                    const float z = acc[k][2 * hi + tt][e] * (tt ? sc1[e] : sc0[e]) + (tt ? sh1[e] : sh0[e]);
+                    v[4 * tt + e] = z >= 0.f ? z : z * (tt ? sl1[e] : sl0[e]);
                 }
             const int cch = co0 + 32 * hi + 8 * q;
             if (p.res) {
@@ -335,12 +334,13 @@ int cin_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     const long long nb = (long long)d.N * p.tiles_x * p.tiles_y;
     if (nb > 0x7fffffffLL || gy > 65535u) { set_error("cin_bf16: grid too large"); return SRMI_EINVAL; }
     const dim3 grid((unsigned)nb, gy);
-    if (tile == 0 && nct == 4) hipLaunchKernelGGL((conv_cin_kernel<6, 6, 4>), grid, dim3(256), 0, s, p);
-    else if (tile == 0) hipLaunchKernelGGL((conv_cin_kernel<6, 6, 2>), grid, dim3(256), 0, s, p);
-    else if (tile == 1 && nct == 4) hipLaunchKernelGGL((conv_cin_kernel<8, 4, 4>), grid, dim3(256), 0, s, p);
-    else if (tile == 1) hipLaunchKernelGGL((conv_cin_kernel<8, 4, 2>), grid, dim3(256), 0, s, p);
-    else if (nct == 4) hipLaunchKernelGGL((conv_cin_kernel<4, 2, 4>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((conv_cin_kernel<4, 2, 2>), grid, dim3(256), 0, s, p);
+    // the two big tiles run with 8 waves (two per SIMD hide each other's LDS / barrier / staging bubbles)
+    if (tile == 0 && nct == 4) hipLaunchKernelGGL((conv_cin_kernel<6, 6, 4, 8>), grid, dim3(512), 0, s, p);
+    else if (tile == 0) hipLaunchKernelGGL((conv_cin_kernel<6, 6, 2, 8>), grid, dim3(512), 0, s, p);
+    else if (tile == 1 && nct == 4) hipLaunchKernelGGL((conv_cin_kernel<8, 4, 4, 8>), grid, dim3(512), 0, s, p);
+    else if (tile == 1) hipLaunchKernelGGL((conv_cin_kernel<8, 4, 2, 8>), grid, dim3(512), 0, s, p);
+    else if (nct == 4) hipLaunchKernelGGL((conv_cin_kernel<4, 2, 4, 4>), grid, dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((conv_cin_kernel<4, 2, 2, 4>), grid, dim3(256), 0, s, p);
     return hip_check(hipGetLastError(), "conv_cin_kernel");
 }
 
