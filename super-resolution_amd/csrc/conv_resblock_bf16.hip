@@ -322,6 +322,7 @@ int resblock_launch(const srmi_conv_args& a1, const srmi_conv_args& a2, hipStrea
     p.epi2.act = d2.act; p.epi2.act_param = d2.act_param; p.epi2.alpha_pc = d2.alpha_per_channel;
     p.N = d1.N; p.H = d1.H; p.W = d1.W; p.in_cs = d1.in_cstride ? d1.in_cstride : 64;
     p.dbg = dbg_flags();
+    if (p.dbg & 512) p.epi2.res = nullptr;     // ablation: no residual read
     if (d1.N == 0 || d1.H == 0 || d1.W == 0) return SRMI_OK;
     const bool big = d1.W > 64 && d1.H >= 6;
     if (big) {

@@ -121,7 +121,8 @@ def test_layout_convert_exact():
     b = Fn.layout_convert(x, 2, 5, 7, 9, L.NCHW, L.NHWC, torch.bfloat16)
     assert torch.equal(b, x.permute(0, 2, 3, 1).contiguous().bfloat16())     # RNE cast matches torch's
     # LDS-transposed NHWC -> NCHW path (C >= 8), ragged in pixels and channels
-    for (n, c, h, w) in [(2, 64, 7, 9), (1, 72, 5, 13), (3, 8, 1, 1)]:
+    # (H*W % 4 == 0 with bf16 input takes the vectorised kernel)
+    for (n, c, h, w) in [(2, 64, 7, 9), (1, 72, 5, 13), (3, 8, 1, 1), (2, 64, 8, 10), (1, 72, 4, 13), (1, 128, 16, 17), (3, 8, 2, 2)]:
         t = torch.from_numpy(g.uniform(-1, 1, (n, h, w, c)).astype(np.float32)).to(DEV)
         assert torch.equal(Fn.layout_convert(t, n, c, h, w, L.NHWC, L.NCHW, torch.float32), t.permute(0, 3, 1, 2).contiguous())
         tb = t.bfloat16()
