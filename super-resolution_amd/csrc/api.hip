@@ -16,7 +16,8 @@ void set_error(const char* fmt, ...) {
 }
 
 // SRMI_DBG: profiling-only ablation switches (results are WRONG with bits 1..16 or 512 set; never set in production).
-//   1/2/4/8/16  fused ResBlock: skip staging / conv 1 / conv 2 / epilogue / T write (phase timing)
+//   1/2/4/8/16  fused ResBlock: skip staging / conv 1 / epilogue / conv 2 / T write (phase timing; 1/2/4 also in the
+//               Cin=64 kernel: staging / MFMA loop / epilogue)
 //   32          disable the XCD-aware block -> tile remap        128  4-wave fused ResBlock
 //   256         4-wave Cin=64 / K-chunked kernels                512  fused ResBlock without the residual read
 int dbg_flags() {
