@@ -96,30 +96,52 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock_c64_kernel(ResBlockParams
     c64_params_load(pregs1, p.epi1, 1, tid);
     c64_params_load(pregs2, p.epi2, 1, tid);
     // ---- stage the x halo tile (2-pixel ring) ----------------------------------------------------
+    // Row-oriented so that almost all index arithmetic is wave-uniform (SALU) or a compile-time immediate: part A
+    // gives a thread one (column, 16-B chunk) and walks the XR rows; part B spreads the XC % (NTH/8) left-over
+    // columns over the threads.  Pixels outside the image are read through a buffer descriptor at an out-of-range
+    // offset, which returns zeros without touching memory (conv1's zero padding) - no per-load select.
     if (!(p.dbg & 1)) {
-        constexpr int NCH = XR * XC * 8;
-        constexpr int NIT = (NCH + NTH - 1) / NTH;
-        const bf16_t* xin = p.x + (size_t)n * p.H * p.W * p.in_cs;
-        u32x4 v[NIT];
+        constexpr int CPT = NTH / 8;                  // columns per pass
+        constexpr int NA = XC / CPT, RB = XC - NA * CPT;
+        constexpr int NB = (XR * RB * 8 + NTH - 1) / NTH;
+        constexpr unsigned OOB_COL = 0x80000000u, OOB_ROW = 0x40000000u;   // image bytes <= 2^30 (checked on the host)
+        const unsigned img_bytes = (unsigned)p.H * p.W * p.in_cs * 2;
+        const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.x + (size_t)n * p.H * p.W * p.in_cs), 0, img_bytes, 0x00020000);
+        const unsigned row_bytes = (unsigned)p.W * p.in_cs * 2;
+        const int ch = tid & 7, c0 = tid >> 3;
+        u32x4 va[NA > 0 ? NA * XR : 1], vb[NB > 0 ? NB : 1];
+        unsigned la[NA > 0 ? NA : 1], lb[NB > 0 ? NB : 1];
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int idx = min(tid + it * NTH, NCH - 1);
-            const int pp = idx >> 3, ch = idx & 7;
-            const int row = pp / XC, col = pp - row * XC;
-            const int gy = min(max(y0 - 2 + row, 0), p.H - 1), gx = min(max(x0 - 2 + col, 0), p.W - 1);
-            v[it] = *(const u32x4*)(xin + ((size_t)gy * p.W + gx) * p.in_cs + ch * 8);
+        for (int g = 0; g < NA; ++g) {
+            const int col = g * CPT + c0, gx = x0 - 2 + col;
+            const unsigned coff = (gx >= 0 && gx < p.W) ? (unsigned)gx * p.in_cs * 2 + ch * 16 : OOB_COL;
+            la[g] = col * 128 + ((ch ^ ((col >> 1) & 7)) << 4);
+#pragma unroll
+            for (int row = 0; row < XR; ++row) {
+                const int gy = y0 - 2 + row;                               // wave-uniform
+                const unsigned roff = (gy >= 0 && gy < p.H) ? (unsigned)gy * row_bytes : OOB_ROW;
+                va[g * XR + row] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, coff + roff, 0, 0));
+            }
         }
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int idx = tid + it * NTH;
-            const int pp = idx >> 3, ch = idx & 7;
-            const int row = pp / XC, col = pp - row * XC;
+        for (int i = 0; i < NB; ++i) {
+            const int sidx = tid + i * NTH;
+            const int row = sidx / (RB * 8), rem = sidx - row * (RB * 8);
+            const int col = NA * CPT + (rem >> 3), chb = rem & 7;
             const int gy = y0 - 2 + row, gx = x0 - 2 + col;
-            u32x4 z = v[it];
-            if (!(gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)) z = (u32x4){0u, 0u, 0u, 0u};
-            const int P = row * ROWP + col;
-            if (idx < NCH) *(u32x4*)(lds + P * 128 + ((ch ^ ((P >> 1) & 7)) << 4)) = z;
+            const bool ok = sidx < XR * RB * 8 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            const unsigned off = ok ? (unsigned)gy * row_bytes + (unsigned)gx * p.in_cs * 2 + chb * 16 : OOB_COL;
+            vb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 0));
+            lb[i] = (row * ROWP + col) * 128 + ((chb ^ ((col >> 1) & 7)) << 4);    // ROWP % 16 == 0: swizzle key from col alone
         }
+#pragma unroll
+        for (int g = 0; g < NA; ++g)
+#pragma unroll
+            for (int row = 0; row < XR; ++row) *(u32x4*)(lds + la[g] + row * (ROWP * 128)) = va[g * XR + row];
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            if (tid + i * NTH < XR * RB * 8) *(u32x4*)(lds + lb[i]) = vb[i];
     }
     c64_params_store(par, pregs1, 1, tid);
     c64_params_store(par + 192, pregs2, 1, tid);
@@ -294,6 +316,8 @@ bool resblock_supported(const srmi_conv_desc& d1, const srmi_conv_desc& d2) {
     if (d1.N != d2.N || d1.H != d2.H || d1.W != d2.W) return false;
     if (d1.out_cstride && d1.out_cstride != 64) return false;   // T must be a plain 64-channel tensor
     if (d1.out_coffset || (d2.in_cstride && d2.in_cstride != 64)) return false;
+    // the staging addresses one image through a 32-bit buffer descriptor with two out-of-range markers
+    if ((unsigned long long)d1.H * d1.W * (d1.in_cstride ? d1.in_cstride : 64) * 2 > (1ull << 30)) return false;
     return true;
 }
 
