@@ -1,6 +1,8 @@
 // Pieces shared by the bf16 MFMA conv kernels that produce 64-channel chunks (conv_c64_bf16.hip,
 // conv_k9c3_bf16.hip): output-channel permutation, epilogue-parameter staging, fused epilogue.
 #pragma once
+#include <type_traits>
+
 #include "common.h"
 
 namespace srmi {
@@ -8,6 +10,16 @@ namespace srmi {
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// Slope activation on a channel pair:  z = a*sc + sh;  z >= 0 ? z : z*sl  with the multiply-adds as packed-f32
+// instructions (v_pk_fma_f32 / v_pk_mul_f32): three VALU instructions per value instead of four.
+__device__ __forceinline__ f32x2 slope_act2(f32x2 a, f32x2 sc, f32x2 sh, f32x2 sl) {
+    const f32x2 z = __builtin_elementwise_fma(a, sc, sh);
+    const f32x2 zs = z * sl;
+    return (f32x2){z[0] >= 0.f ? z[0] : zs[0], z[1] >= 0.f ? z[1] : zs[1]};
+}
 
 // store modes
 enum { C64_PLAIN = 0, C64_CRD = 1, C64_DCR = 2 };
@@ -83,7 +95,7 @@ template <int PT, bool PRE = false>
 __device__ __forceinline__ void c64_epilogue(const f32x4 (&acc)[PT][4], const float* par_s, const C64Epi& o, int s,
                                              int n, int y0, int x0, const int (&prow)[PT], const int (&pcol)[PT],
                                              int pl, int q, const u32x4 (*rpre)[2] = nullptr) {
-    float sc[16], sh[16], sl[16];
+    f32x2 sc[8], sh[8], sl[8];     // channel pairs, in the order of this lane's 16 values
 #pragma unroll
     for (int hi = 0; hi < 2; ++hi)
 #pragma unroll
@@ -93,27 +105,32 @@ __device__ __forceinline__ void c64_epilogue(const f32x4 (&acc)[PT][4], const fl
             const f32x4 bsh = *(const f32x4*)(par_s + 64 + c);
             const f32x4 csl = *(const f32x4*)(par_s + 128 + c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                sc[8 * hi + 4 * v4 + e] = a[e];
-                sh[8 * hi + 4 * v4 + e] = bsh[e];
-                sl[8 * hi + 4 * v4 + e] = csl[e];
+            for (int e = 0; e < 2; ++e) {
+                sc[4 * hi + 2 * v4 + e] = (f32x2){a[2 * e], a[2 * e + 1]};
+                sh[4 * hi + 2 * v4 + e] = (f32x2){bsh[2 * e], bsh[2 * e + 1]};
+                sl[4 * hi + 2 * v4 + e] = (f32x2){csl[2 * e], csl[2 * e + 1]};
             }
         }
     const int si = s >> 1, sj = s & 1;
-    const int Cf = o.mode == C64_PLAIN ? o.Cout : 64;
-    const int cbase = (o.mode == C64_PLAIN ? 64 * s : 0) + 8 * q;
-    size_t pix[PT];
-    bool ok[PT];
-    // opaque zero: keeps hipcc from hoisting the address arithmetic above the K loop (it would be spilled
-    // to scratch there: the loops run at the 512-register limit)
+    const bool plain = o.mode == C64_PLAIN;
+    const int Cf = plain ? o.Cout : 64;
+    const int cbase = (plain ? 64 * s : 0) + 8 * q;
+    const int Hs = plain ? o.H : 2 * o.H, Ws = plain ? o.W : 2 * o.W;      // output image
+    // A pixel tile is one image row segment: its row is wave-uniform, so the 64-bit part of every address (image, row)
+    // is scalar arithmetic and a lane adds a 32-bit in-row offset.
+    // opaque zero: keeps hipcc from hoisting the lane arithmetic above the K loop (it would be spilled to scratch
+    // there: the loops run at the register limit)
     int opaque0;
     asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));
+    size_t rowpix[PT];
+    int ocol[PT];
+    bool ok[PT];
 #pragma unroll
     for (int k = 0; k < PT; ++k) {
         const int oy = y0 + prow[k], ox = x0 + pcol[k] + pl + opaque0;
         ok[k] = oy < o.H && ox < o.W;
-        pix[k] = o.mode == C64_PLAIN ? ((size_t)n * o.H + oy) * o.W + ox
-                                     : ((size_t)n * 2 * o.H + 2 * oy + si) * (2 * o.W) + 2 * ox + sj;
+        rowpix[k] = ((size_t)n * Hs + (plain ? oy : 2 * oy + si)) * Ws;
+        ocol[k] = plain ? ox : 2 * ox + sj;
     }
     u32x4 r[PT][2];
     const bool have_res = PRE || o.res != nullptr;
@@ -126,44 +143,42 @@ __device__ __forceinline__ void c64_epilogue(const f32x4 (&acc)[PT][4], const fl
             r[k][0] = (u32x4){0u, 0u, 0u, 0u};
             r[k][1] = (u32x4){0u, 0u, 0u, 0u};
             if (ok[k]) {
-                const bf16_t* rp = o.res + pix[k] * Cf + cbase;
+                const bf16_t* rp = o.res + rowpix[k] * Cf + (unsigned)(ocol[k] * Cf + cbase);
                 r[k][0] = *(const u32x4*)rp;
                 r[k][1] = *(const u32x4*)(rp + 32);
             }
         }
     }
+    // SLOPE = false: no activation (slope 1 everywhere, e.g. the second conv of a ResBlock) - skips the select
+    auto body = [&](auto SLOPE) {
 #pragma unroll
-    for (int k = 0; k < PT; ++k) {
-        float v[16];
-#pragma unroll
-        for (int t = 0; t < 4; ++t)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int c = 4 * t + e;
-                const float z = acc[k][t][e] * sc[c] + sh[c];
-                v[c] = z >= 0.f ? z : z * sl[c];
-            }
-        if (have_res) {
-#pragma unroll
-            for (int hi = 0; hi < 2; ++hi)
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[8 * hi + 2 * e] += bf2f((bf16_t)(r[k][hi][e] & 0xffffu));
-                    v[8 * hi + 2 * e + 1] += bf2f((bf16_t)(r[k][hi][e] >> 16));
-                }
-        }
-        if (ok[k]) {
+        for (int k = 0; k < PT; ++k) {
             u32x4 o0, o1;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                o0[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
-                o1[e] = pack_bf2(v[8 + 2 * e], v[8 + 2 * e + 1]);
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    const int j = 2 * t + e;                     // channel pair of this lane's 16 values
+                    const f32x2 a = {acc[k][t][2 * e], acc[k][t][2 * e + 1]};
+                    f32x2 v;
+                    if constexpr (decltype(SLOPE)::value) v = slope_act2(a, sc[j], sh[j], sl[j]);
+                    else v = __builtin_elementwise_fma(a, sc[j], sh[j]);
+                    if (have_res) {
+                        const unsigned w = r[k][j >> 2][j & 3];
+                        v += (f32x2){__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
+                    }
+                    const unsigned w = pack_bf2(v[0], v[1]);
+                    if (t < 2) o0[j & 3] = w; else o1[j & 3] = w;
+                }
+            if (ok[k]) {
+                bf16_t* op = o.y + rowpix[k] * o.out_cs + (unsigned)(ocol[k] * o.out_cs + o.out_co + cbase);
+                *(u32x4*)op = o0;
+                *(u32x4*)(op + 32) = o1;
             }
-            bf16_t* op = o.y + pix[k] * o.out_cs + o.out_co + cbase;
-            *(u32x4*)op = o0;
-            *(u32x4*)(op + 32) = o1;
         }
-    }
+    };
+    if (o.act == SRMI_ACT_NONE) body(std::false_type{});
+    else body(std::true_type{});
 }
 
 // scheduling directive: NR groups of {1 LDS read, ~NM/NR MFMAs} (compile-time only, no code emitted)

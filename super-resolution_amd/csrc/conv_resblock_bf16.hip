@@ -159,16 +159,20 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock_c64_kernel(ResBlockParams
 
     // ================= phase 1: conv1 over the flattened T region =================================
     int boff1[PT1][3];
+    unsigned inside = 0;     // bit k: this lane's pixel of tile k lies inside the image (else T = 0: conv2's zero padding)
 #pragma unroll
     for (int k = 0; k < PT1; ++k) {
         const int pix = min((wave * PT1 + k) * 16 + pl, TR * TC - 1);   // padding tiles recompute the last pixel
         const int ti = pix / TC, tj = pix - ti * TC;
+        const int gy = y0 - 1 + ti, gx = x0 - 1 + tj;
+        inside |= (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? 1u << k : 0u;
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
             const int P = ti * ROWP + tj + dx;
             boff1[k][dx] = P * 128 + ((q ^ ((P >> 1) & 7)) << 4);
         }
     }
+    asm volatile("" : "+v"(inside));      // materialise the mask HERE (hipcc would sink it below the K loop and keep its 2*PT1 inputs alive)
     {
         f32x4 acc[PT1][4];
 #pragma unroll
@@ -206,7 +210,9 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock_c64_kernel(ResBlockParams
         }
 
         // ---- phase 2: T = act(affine1(acc)) as bf16 over the x tile (zero outside the image) ----
-        float sc[16], sh[16], sl[16];
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();           // every wave has finished reading the x tile
+        f32x2 sc[8], sh[8], sl[8];
 #pragma unroll
         for (int hi = 0; hi < 2; ++hi)
 #pragma unroll
@@ -216,46 +222,31 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock_c64_kernel(ResBlockParams
                 const f32x4 bsh = *(const f32x4*)(par + 64 + c);
                 const f32x4 csl = *(const f32x4*)(par + 128 + c);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    sc[8 * hi + 4 * v4 + e] = a[e];
-                    sh[8 * hi + 4 * v4 + e] = bsh[e];
-                    sl[8 * hi + 4 * v4 + e] = csl[e];
+                for (int e = 0; e < 2; ++e) {
+                    sc[4 * hi + 2 * v4 + e] = (f32x2){a[2 * e], a[2 * e + 1]};
+                    sh[4 * hi + 2 * v4 + e] = (f32x2){bsh[2 * e], bsh[2 * e + 1]};
+                    sl[4 * hi + 2 * v4 + e] = (f32x2){csl[2 * e], csl[2 * e + 1]};
                 }
             }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();           // every wave has finished reading the x tile
-        // opaque zero: keeps hipcc from hoisting this phase's address arithmetic above the K loop, where it
-        // would be spilled to scratch (the loop runs at the 512-register limit)
-        int opaque0;
-        asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));
+        // T pixel (ti, tj) lives where x pixel (ti, tj) lived: boff1[k][0] IS the address of its chunk q, and chunk
+        // 4+q is 64 B further (q ^ 4 under the swizzle).  Lanes / tiles past the end of the T region were clamped to
+        // its last pixel: they hold the same values and write them to the same place.
         if (!(p.dbg & 16))
 #pragma unroll
         for (int k = 0; k < PT1; ++k) {
-            const int pix = min((wave * PT1 + k) * 16 + pl + opaque0, TR * TC - 1);
-            const int ti = pix / TC, tj = pix - ti * TC;
-            const int gy = y0 - 1 + ti, gx = x0 - 1 + tj;
-            const unsigned keep = (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? 0xffffffffu : 0u;
-            float v[16];
+            const unsigned keep = (unsigned)((int)(inside << (31 - k)) >> 31);
+            u32x4 o0, o1;
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int c = 4 * t + e;
-                    const float z = acc[k][t][e] * sc[c] + sh[c];
-                    v[c] = z >= 0.f ? z : z * sl[c];
+                for (int e = 0; e < 2; ++e) {
+                    const f32x2 v = slope_act2((f32x2){acc[k][t][2 * e], acc[k][t][2 * e + 1]}, sc[2 * t + e], sh[2 * t + e],
+                                               sl[2 * t + e]);
+                    const unsigned w = pack_bf2(v[0], v[1]) & keep;       // channels 4t+2e, +1 of this lane's 16
+                    if (t < 2) o0[2 * t + e] = w; else o1[2 * (t - 2) + e] = w;
                 }
-            u32x4 o0, o1;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {      // zero padding of conv2: select on the packed words
-                o0[e] = pack_bf2(v[2 * e], v[2 * e + 1]) & keep;
-                o1[e] = pack_bf2(v[8 + 2 * e], v[8 + 2 * e + 1]) & keep;
-            }
-            if ((wave * PT1 + k) * 16 + pl + opaque0 < TR * TC) {
-                const int P = ti * ROWP + tj;
-                const int sw = (P >> 1) & 7;
-                *(u32x4*)(lds + P * 128 + ((q ^ sw) << 4)) = o0;          // channels 8q .. 8q+7   = chunk q
-                *(u32x4*)(lds + P * 128 + (((4 + q) ^ sw) << 4)) = o1;    // channels 32+8q ..     = chunk 4+q
-            }
+            *(u32x4*)(lds + boff1[k][0]) = o0;            // channels 8q .. 8q+7     = chunk q
+            *(u32x4*)(lds + (boff1[k][0] ^ 64)) = o1;     // channels 32+8q ..       = chunk 4+q
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();           // T complete
@@ -263,6 +254,10 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock_c64_kernel(ResBlockParams
         // ================= phase 3: conv2 from T ==================================================
         int prow[PT2], pcol[PT2];
         int boff2[PT2][3];
+        // opaque zero: keeps hipcc from hoisting this phase's address arithmetic above conv1's K loop, where it would
+        // be spilled to scratch (the loop runs at the register limit)
+        int opaque0;
+        asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));
 #pragma unroll
         for (int k = 0; k < PT2; ++k) {
             const int t = min(wave * PT2 + k, NPT2 - 1);
@@ -270,7 +265,7 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock_c64_kernel(ResBlockParams
             pcol[k] = (t - prow[k] * TWT) * 16;
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                const int P = prow[k] * ROWP + pcol[k] + pl + dx;
+                const int P = prow[k] * ROWP + pcol[k] + pl + opaque0 + dx;
                 boff2[k][dx] = P * 128 + ((q ^ ((P >> 1) & 7)) << 4);
             }
             if (wave * PT2 + k >= NPT2) prow[k] = 1 << 20;     // padding tile: the epilogue's bounds check drops it
