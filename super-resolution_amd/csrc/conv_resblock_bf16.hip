@@ -12,9 +12,9 @@
 //            8 x 98 pixels, 13 per wave) so the halo ring costs 1.44x, not 1.56x, of a tile's MFMAs;
 //   phase 2  barrier; T = act(affine1(acc)) -> bf16, zero outside the image (conv2's zero padding),
 //            written over the x tile in the same swizzled layout; barrier;
-//   phase 3  conv2 from T exactly like conv_c64_kernel; epilogue adds x (re-read from L2/MALL) and stores.
-//            (Keeping the 72 residual registers per lane across phases 2-3 was tried: hipcc spills them to
-//            scratch at the 512-register limit, which costs what the re-read costs.)
+//   phase 3  conv2 from T exactly like conv_c64_kernel; epilogue adds x and stores.  With 8 waves (5 pixel tiles
+//            per wave) x is lifted out of the LDS tile into 40 registers just before T overwrites it; with 4 waves
+//            (9 tiles, 72 registers: hipcc spills them at the 512-register limit) it is re-read from L2.
 //   Weights: both convs' packed A fragments stream through a 4-slot x 4 KiB LDS-DMA ring, one K-step
 //   (4 fragments) per slot, three steps ahead, across the phase boundary; hand-off per step =
 //   counted vmcnt + s_barrier (slot j-1 is re-filled at barrier j: its readers are provably done).
@@ -30,6 +30,7 @@ struct ResBlockParams {
     C64Epi epi2;   // scale/shift/act of conv2, residual, output
     int N, H, W, in_cs;
     int tiles_x, tiles_y;
+    int res_is_x;   // the residual is the block's own input (same pointer, 64-channel pixels): it can come from the LDS tile
     int dbg;  // ablation (SRMI_DBG env, investigation only): 1 skip staging, 2 skip conv1 K loop, 8 skip conv2 K loop, 4 skip epilogue, 16 skip T write
 };
 
@@ -210,6 +211,23 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock_c64_kernel(ResBlockParams
         }
 
         // ---- phase 2: T = act(affine1(acc)) as bf16 over the x tile (zero outside the image) ----
+        // The residual IS the centre of the x tile: take it from LDS now (the operand fragments are dead, T is about
+        // to overwrite the tile) instead of re-reading it from L2 in the epilogue.  PT2 * 8 registers, kept across
+        // conv2; worth it while they fit (8-wave variant, small tile) - at 9 tiles per wave hipcc spills them.
+        constexpr bool RES_LDS = PT2 * 8 <= 40;
+        u32x4 rpre[RES_LDS ? PT2 : 1][2];
+        if constexpr (RES_LDS) {
+            if (p.res_is_x) {
+#pragma unroll
+                for (int k = 0; k < PT2; ++k) {
+                    const int t = min(wave * PT2 + k, NPT2 - 1);
+                    const int P = (t / TWT + 2) * ROWP + (t % TWT) * 16 + pl + 2;
+                    const int a0 = P * 128 + ((q ^ ((P >> 1) & 7)) << 4);
+                    rpre[k][0] = *(const u32x4*)(lds + a0);
+                    rpre[k][1] = *(const u32x4*)(lds + (a0 ^ 64));
+                }
+            }
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();           // every wave has finished reading the x tile
         f32x2 sc[8], sh[8], sl[8];
@@ -301,7 +319,14 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock_c64_kernel(ResBlockParams
                     acc2[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[j & 1][t], bfr2[j & 1][k], acc2[k][t], 0, 0, 0);
             if (j + 1 < 18) sched_interleave<0, 4 + PT2, 4 * PT2>();
         }
-        if (!(p.dbg & 4)) c64_epilogue<PT2>(acc2, par + 192, p.epi2, 0, n, y0, x0, prow, pcol, pl, q);
+        if (!(p.dbg & 4)) {
+            if constexpr (RES_LDS) {
+                if (p.res_is_x) c64_epilogue<PT2, true>(acc2, par + 192, p.epi2, 0, n, y0, x0, prow, pcol, pl, q, rpre);
+                else c64_epilogue<PT2>(acc2, par + 192, p.epi2, 0, n, y0, x0, prow, pcol, pl, q);
+            } else {
+                c64_epilogue<PT2>(acc2, par + 192, p.epi2, 0, n, y0, x0, prow, pcol, pl, q);
+            }
+        }
     }
 }
 
@@ -342,6 +367,8 @@ int resblock_launch(const srmi_conv_args& a1, const srmi_conv_args& a2, hipStrea
     p.N = d1.N; p.H = d1.H; p.W = d1.W; p.in_cs = d1.in_cstride ? d1.in_cstride : 64;
     p.dbg = dbg_flags();
     if (p.dbg & 512) p.epi2.res = nullptr;     // ablation: no residual read
+    p.res_is_x = p.epi2.res != nullptr && (const void*)p.epi2.res == (const void*)p.x && p.in_cs == 64 && !(p.dbg & 2048);
+    if (p.dbg & 1024) p.epi2.H = 0;            // ablation: epilogue arithmetic only (every pixel fails the bounds check: no loads, no stores)
     if (d1.N == 0 || d1.H == 0 || d1.W == 0) return SRMI_OK;
     const bool big = d1.W > 64 && d1.H >= 6;
     if (big) {

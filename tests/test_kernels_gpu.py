@@ -269,6 +269,8 @@ def test_k9c3_kernel(case):
     dict(N=1, H=13, W=100),            # big 6x96 tiles, ragged both ways
     dict(N=2, H=6, W=96),              # exactly one big tile per image
     dict(N=1, H=24, W=192),
+    dict(N=1, H=13, W=100, other_res=True),     # the residual is NOT the block input: read from memory, not from the LDS tile
+    dict(N=2, H=11, W=13, other_res=True),
 ])
 def test_fused_resblock_kernel(case):
     """ResBlock in one launch == conv-affine-PReLU -> (bf16 T) -> conv-affine -> +x, the intermediate rounded to
@@ -284,21 +286,25 @@ def test_fused_resblock_kernel(case):
         scs.append(torch.from_numpy(g.uniform(0.5, 1.5, 64).astype(np.float32)))
         shs.append(torch.from_numpy(g.uniform(-0.3, 0.3, 64).astype(np.float32)))
     alpha = torch.tensor([0.25])
+    res = x
+    if case.get("other_res"):
+        res = torch.from_numpy(g.uniform(-1, 1, (N, 64, H, W)).astype(np.float32)).bfloat16().float()
     t_ref = _ref_fused(x, ws[0], scs[0], shs[0], L.ACT_PRELU, 0.0, alpha, None, 1, 1, 1, False).float().bfloat16().float()
-    ref = _ref_fused(t_ref, ws[1], scs[1], shs[1], L.ACT_NONE, 0.0, None, x, 1, 1, 1, False)
+    ref = _ref_fused(t_ref, ws[1], scs[1], shs[1], L.ACT_NONE, 0.0, None, res, 1, 1, 1, False)
 
     def desc(act):
         return Fn.make_desc(N, H, W, 64, 64, 3, in_dtype=L.BF16, out_dtype=L.BF16, res_dtype=L.BF16,
                             compute=L.COMPUTE_BF16, act=act)
     d1, d2 = desc(L.ACT_PRELU), desc(L.ACT_NONE)
     xd = x.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
+    rd = xd if res is x else res.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
     wp = [Fn.pack_weights(d1, ws[0].to(DEV)), Fn.pack_weights(d2, ws[1].to(DEV))]
     scd, shd, ad = [t.to(DEV) for t in scs], [t.to(DEV) for t in shs], alpha.to(DEV)
     tmp = torch.full((N, H, W, 64), 3.0, dtype=torch.bfloat16, device=DEV)
     y = torch.full((N, H, W, 64), -5.0, dtype=torch.bfloat16, device=DEV)
     a1, a2 = L.ConvArgs(), L.ConvArgs()
     Fn.fill_args(a1, d1, xd, wp[0], scd[0], shd[0], ad, None, tmp)
-    Fn.fill_args(a2, d2, tmp, wp[1], scd[1], shd[1], None, xd, y)
+    Fn.fill_args(a2, d2, tmp, wp[1], scd[1], shd[1], None, rd, y)
     a1.flags = L.CONV_FUSE_NEXT
     assert L.load().srmi_conv2d_can_fuse(C.byref(a1), C.byref(a2)) == 1
     L.check(L.load().srmi_resblock_fwd(C.byref(a1), C.byref(a2), Fn.stream_ptr()))
@@ -310,7 +316,7 @@ def test_fused_resblock_kernel(case):
     # unfused pair through the same ABI
     y2 = torch.empty_like(y)
     Fn.conv2d_fused(d1, xd, wp[0], scd[0], shd[0], ad, None, out=tmp)
-    Fn.conv2d_fused(d2, tmp, wp[1], scd[1], shd[1], None, xd, out=y2)
+    Fn.conv2d_fused(d2, tmp, wp[1], scd[1], shd[1], None, rd, out=y2)
     torch.cuda.synchronize()
     assert torch.equal(y, y2)
     # aliasing the input is refused before any launch
