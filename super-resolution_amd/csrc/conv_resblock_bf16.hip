@@ -34,27 +34,35 @@ struct ResBlockParams {
     int dbg;  // ablation (SRMI_DBG env, investigation only): 1 skip staging, 2 skip conv1 K loop, 8 skip conv2 K loop, 4 skip epilogue, 16 skip T write
 };
 
-constexpr int RB_SLOTS = 4;
 constexpr int RB_STEP_BYTES = 4096;   // one K-step: 4 channel tiles x 64 lanes x 16 B
 
 // NW = waves per workgroup: 4 (one per SIMD, 512 registers each) or 8 (two per SIMD, 256 each: the second wave
 // of a SIMD fills the first one's LDS / barrier / VALU-epilogue bubbles; same tile, same LDS, half the pixel
 // tiles per wave).
-template <int TH, int TWT, int NW>
-__global__ __launch_bounds__(NW * 64, 1) void resblock_c64_kernel(ResBlockParams p) {
+//
+// SLOTS = depth of the weight ring (K-steps), WGPC = workgroups per CU the register budget is cut for.  The 6 x 48 tile
+// with 4 waves and a 3-slot ring needs 78.5 KiB of LDS and 256 registers: TWO workgroups share a CU, and while one
+// sits in a phase that leaves the matrix cores idle (launch, staging, T write-back, epilogue, store drain) the other
+// one computes - provided they are out of phase, which two streams (or several rounds) give.
+template <int TH, int TWT, int NW, int SLOTS, int WGPC>
+__global__ __launch_bounds__(NW * 64, WGPC) void resblock_c64_kernel(ResBlockParams p) {
     constexpr int NTH = NW * 64;
     constexpr int TW = TWT * 16;
     constexpr int XR = TH + 4, XC = TW + 4;          // x halo tile
     constexpr int TR = TH + 2, TC = TW + 2;          // T region
-    constexpr int ROWP = (XC + 15) / 16 * 16;        // LDS row pitch in pixels (multiple of 16)
+    constexpr int ROWP = WGPC > 1 ? XC : (XC + 15) / 16 * 16;   // LDS row pitch in pixels: even, so a row starts on a 256-B bank row and
+                                                     // the swizzle key (col >> 1) & 7 is the same for every row (tap dy = +pitch)
+    static_assert(ROWP % 2 == 0, "pixel pairs must not straddle rows");
+    // swizzle key of LDS pixel P = row * ROWP + col (the P form keeps fewer values alive when the pitch allows it)
+    auto swz = [](int P, int col) { return ROWP % 16 == 0 ? (P >> 1) & 7 : (col >> 1) & 7; };
     constexpr int IN_BYTES = XR * ROWP * 128;
     constexpr int NT1 = (TR * TC + 15) / 16;         // flattened 16-pixel tiles of the T region
     constexpr int PT1 = (NT1 + NW - 1) / NW;
     constexpr int NPT2 = TH * TWT;
     constexpr int PT2 = (NPT2 + NW - 1) / NW;          // waves past the end recompute the last tile and store nothing
-    __shared__ __attribute__((aligned(16))) unsigned char lds[IN_BYTES + RB_SLOTS * RB_STEP_BYTES + 2 * 768];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[IN_BYTES + SLOTS * RB_STEP_BYTES + 2 * 768];
     unsigned char* const wring = lds + IN_BYTES;
-    float* const par = (float*)(lds + IN_BYTES + RB_SLOTS * RB_STEP_BYTES);
+    float* const par = (float*)(lds + IN_BYTES + SLOTS * RB_STEP_BYTES);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -76,7 +84,7 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock_c64_kernel(ResBlockParams
         const unsigned char* base = (const unsigned char*)(g < 18 ? p.w1 : p.w2);
         const unsigned char* src = base + (size_t)(g < 18 ? g : g - 18) * RB_STEP_BYTES + wave * 1024 + lane * 16;
         const unsigned dst = __builtin_amdgcn_readfirstlane(
-            wring_lds + (unsigned)((g & (RB_SLOTS - 1)) * RB_STEP_BYTES + wave * 1024));
+            wring_lds + (unsigned)((g % SLOTS) * RB_STEP_BYTES + wave * 1024));
         unsigned keep;
         if (wave < 4)      // a K-step is 4 KiB = four 1-KiB DMA instructions: waves 4..7 (NW = 8) issue none
         asm volatile(
@@ -89,9 +97,8 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock_c64_kernel(ResBlockParams
             : "v"(src), "s"(dst)
             : "memory");
     };
-    issue_step(0);
-    issue_step(1);
-    issue_step(2);
+#pragma unroll
+    for (int g = 0; g < SLOTS - 1; ++g) issue_step(g);
 
     C64ParRegs pregs1, pregs2;
     c64_params_load(pregs1, p.epi1, 1, tid);
@@ -134,7 +141,7 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock_c64_kernel(ResBlockParams
             const bool ok = sidx < XR * RB * 8 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
             const unsigned off = ok ? (unsigned)gy * row_bytes + (unsigned)gx * p.in_cs * 2 + chb * 16 : OOB_COL;
             vb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 0));
-            lb[i] = (row * ROWP + col) * 128 + ((chb ^ ((col >> 1) & 7)) << 4);    // ROWP % 16 == 0: swizzle key from col alone
+            lb[i] = (row * ROWP + col) * 128 + ((chb ^ ((col >> 1) & 7)) << 4);
         }
 #pragma unroll
         for (int g = 0; g < NA; ++g)
@@ -151,11 +158,12 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock_c64_kernel(ResBlockParams
 
     // one K-step hand-off: step g+1 landed (own copy: counted vmcnt, others': barrier); slot of step g-1
     // is free (its fragments were consumed by the MFMAs of step g-1, which every wave has issued).
+    // (steps up to g+SLOTS-2 are in flight here; SLOTS-3 of them may stay so)
     auto handoff = [&](int g) {
-        if (g + 2 < 36) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        if (SLOTS >= 4 && g + 2 < 36) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (g + 3 < 36) issue_step(g + 3);
+        if (g + SLOTS - 1 < 36) issue_step(g + SLOTS - 1);
     };
 
     // ================= phase 1: conv1 over the flattened T region =================================
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock_c64_kernel(ResBlockParams
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
             const int P = ti * ROWP + tj + dx;
-            boff1[k][dx] = P * 128 + ((q ^ ((P >> 1) & 7)) << 4);
+            boff1[k][dx] = P * 128 + ((q ^ swz(P, tj + dx)) << 4);
         }
     }
     asm volatile("" : "+v"(inside));      // materialise the mask HERE (hipcc would sink it below the K loop and keep its 2*PT1 inputs alive)
@@ -190,7 +198,7 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock_c64_kernel(ResBlockParams
         for (int j = 0; j < 18; ++j) {
             handoff(j);
             {   // prefetch the fragments of global step j+1 (step 18 = first step of conv2: weights only)
-                const unsigned char* wslot = wring + ((j + 1) & (RB_SLOTS - 1)) * RB_STEP_BYTES + lane * 16;
+                const unsigned char* wslot = wring + ((j + 1) % SLOTS) * RB_STEP_BYTES + lane * 16;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) afr[(j + 1) & 1][t] = *(const bf16x8*)(wslot + t * 1024);
                 if (j + 1 < 18) {
@@ -221,8 +229,9 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock_c64_kernel(ResBlockParams
 #pragma unroll
                 for (int k = 0; k < PT2; ++k) {
                     const int t = min(wave * PT2 + k, NPT2 - 1);
-                    const int P = (t / TWT + 2) * ROWP + (t % TWT) * 16 + pl + 2;
-                    const int a0 = P * 128 + ((q ^ ((P >> 1) & 7)) << 4);
+                    const int col = (t % TWT) * 16 + pl + 2;
+                    const int P = (t / TWT + 2) * ROWP + col;
+                    const int a0 = P * 128 + ((q ^ swz(P, col)) << 4);
                     rpre[k][0] = *(const u32x4*)(lds + a0);
                     rpre[k][1] = *(const u32x4*)(lds + (a0 ^ 64));
                 }
@@ -283,8 +292,9 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock_c64_kernel(ResBlockParams
             pcol[k] = (t - prow[k] * TWT) * 16;
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
-                const int P = prow[k] * ROWP + pcol[k] + pl + opaque0 + dx;
-                boff2[k][dx] = P * 128 + ((q ^ ((P >> 1) & 7)) << 4);
+                const int col = pcol[k] + pl + opaque0 + dx;
+                const int P = prow[k] * ROWP + col;
+                boff2[k][dx] = P * 128 + ((q ^ swz(P, col)) << 4);
             }
             if (wave * PT2 + k >= NPT2) prow[k] = 1 << 20;     // padding tile: the epilogue's bounds check drops it
         }
@@ -302,7 +312,7 @@ __global__ __launch_bounds__(NW * 64, 1) void resblock_c64_kernel(ResBlockParams
             const int g = 18 + j;
             if (g + 1 < 36) {
                 handoff(g);
-                const unsigned char* wslot = wring + ((g + 1) & (RB_SLOTS - 1)) * RB_STEP_BYTES + lane * 16;
+                const unsigned char* wslot = wring + ((g + 1) % SLOTS) * RB_STEP_BYTES + lane * 16;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) afr[(j + 1) & 1][t] = *(const bf16x8*)(wslot + t * 1024);
                 const int tapn = (j + 1) >> 1, halfn = (j + 1) & 1;
@@ -371,17 +381,22 @@ int resblock_launch(const srmi_conv_args& a1, const srmi_conv_args& a2, hipStrea
     if (p.dbg & 1024) p.epi2.H = 0;            // ablation: epilogue arithmetic only (every pixel fails the bounds check: no loads, no stores)
     if (d1.N == 0 || d1.H == 0 || d1.W == 0) return SRMI_OK;
     const bool big = d1.W > 64 && d1.H >= 6;
-    if (big) {
+    if (big && (p.dbg & 4096)) {        // 6 x 48 tiles, two workgroups per CU
+        p.tiles_x = (d1.W + 47) / 48; p.tiles_y = (d1.H + 5) / 6;
+        const long long nb = (long long)d1.N * p.tiles_x * p.tiles_y;
+        if (nb > 0x7fffffffLL) { set_error("resblock_bf16: grid too large"); return SRMI_EINVAL; }
+        hipLaunchKernelGGL((resblock_c64_kernel<6, 3, 4, 3, 2>), dim3((unsigned)nb), dim3(256), 0, s, p);
+    } else if (big) {
         p.tiles_x = (d1.W + 95) / 96; p.tiles_y = (d1.H + 5) / 6;
         const long long nb = (long long)d1.N * p.tiles_x * p.tiles_y;
         if (nb > 0x7fffffffLL) { set_error("resblock_bf16: grid too large"); return SRMI_EINVAL; }
-        if (p.dbg & 128) hipLaunchKernelGGL((resblock_c64_kernel<6, 6, 4>), dim3((unsigned)nb), dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((resblock_c64_kernel<6, 6, 8>), dim3((unsigned)nb), dim3(512), 0, s, p);
+        if (p.dbg & 128) hipLaunchKernelGGL((resblock_c64_kernel<6, 6, 4, 4, 1>), dim3((unsigned)nb), dim3(256), 0, s, p);
+        else hipLaunchKernelGGL((resblock_c64_kernel<6, 6, 8, 4, 1>), dim3((unsigned)nb), dim3(512), 0, s, p);
     } else {
         p.tiles_x = (d1.W + 31) / 32; p.tiles_y = (d1.H + 3) / 4;
         const long long nb = (long long)d1.N * p.tiles_x * p.tiles_y;
         if (nb > 0x7fffffffLL) { set_error("resblock_bf16: grid too large"); return SRMI_EINVAL; }
-        hipLaunchKernelGGL((resblock_c64_kernel<4, 2, 4>), dim3((unsigned)nb), dim3(256), 0, s, p);
+        hipLaunchKernelGGL((resblock_c64_kernel<4, 2, 4, 4, 1>), dim3((unsigned)nb), dim3(256), 0, s, p);
     }
     return hip_check(hipGetLastError(), "resblock_c64_kernel");
 }
