@@ -266,6 +266,18 @@ int srmi_conv2d_fwd_seq(const srmi_conv_args* a, int32_t n, void* stream) {
     if (n < 0 || (n > 0 && !a)) { set_error("fwd_seq: bad arguments"); return SRMI_EINVAL; }
     for (int32_t i = 0; i < n; ++i) {
         if ((a[i].flags & SRMI_CONV_FUSE_NEXT) && i + 1 < n && can_fuse_pair(a + i, a + i + 1)) {
+            // a run of fusable pairs that feed each other goes out as ONE persistent launch when every tile fits the GPU
+            int32_t pairs = 1;
+            while (i + 2 * pairs + 1 < n && (a[i + 2 * pairs].flags & SRMI_CONV_FUSE_NEXT) &&
+                   can_fuse_pair(a + i + 2 * pairs, a + i + 2 * pairs + 1))
+                ++pairs;
+            const int m = resblock_chain_length(a + i, pairs);
+            if (m >= 2) {
+                int rc = resblock_chain_launch(a + i, m, (hipStream_t)stream);
+                if (rc) return rc;
+                i += 2 * m - 1;
+                continue;
+            }
             int rc = resblock_launch(a[i], a[i + 1], (hipStream_t)stream);
             if (rc) return rc;
             ++i;
@@ -275,6 +287,21 @@ int srmi_conv2d_fwd_seq(const srmi_conv_args* a, int32_t n, void* stream) {
         if (rc) return rc;
     }
     return SRMI_OK;
+}
+
+// investigation only, not declared in srmi.h: phase time stamps of the last traced chain launch (SRMI_DBG bit 16384)
+int srmi_debug_chain_trace(unsigned long long* out, int n) { return resblock_chain_trace(out, n); }
+
+int srmi_chain_enable(int32_t on) {
+    return resblock_chain_enable(on);
+}
+
+int srmi_chain_status(uint32_t* timeouts) {
+    if (!timeouts) { set_error("chain_status: NULL argument"); return SRMI_EINVAL; }
+    unsigned c = 0;
+    int rc = resblock_chain_timeouts(&c);
+    *timeouts = c;
+    return rc;
 }
 
 int srmi_layout_convert(const void* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t src_layout,
