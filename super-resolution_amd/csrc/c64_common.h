@@ -21,6 +21,14 @@ __device__ __forceinline__ f32x2 slope_act2(f32x2 a, f32x2 sc, f32x2 sh, f32x2 s
     return (f32x2){z[0] >= 0.f ? z[0] : zs[0], z[1] >= 0.f ? z[1] : zs[1]};
 }
 
+// The same for slopes known to lie in [0, 1] (ReLU, LeakyReLU, a scalar PReLU alpha in that range, none):
+// max(z, z*sl) is then the identical value and costs one instruction instead of a compare + select.
+__device__ __forceinline__ f32x2 slope_act2_max(f32x2 a, f32x2 sc, f32x2 sh, f32x2 sl) {
+    const f32x2 z = __builtin_elementwise_fma(a, sc, sh);
+    const f32x2 zs = z * sl;
+    return (f32x2){__builtin_fmaxf(z[0], zs[0]), __builtin_fmaxf(z[1], zs[1])};
+}
+
 // store modes
 enum { C64_PLAIN = 0, C64_CRD = 1, C64_DCR = 2 };
 
@@ -43,6 +51,18 @@ struct C64Epi {
     int H, W, Cout, out_cs, out_co, mode;
     int act; float act_param; int alpha_pc;
 };
+
+// 0: no activation, 1: one slope in [0, 1] for every channel (max form), 2: general (compare + select).  Wave-uniform.
+__device__ __forceinline__ int c64_slope_kind(const C64Epi& e) {
+    if (e.act == SRMI_ACT_NONE) return 0;
+    if (e.act == SRMI_ACT_PRELU && e.alpha_pc) return 2;
+    float s = 1.f;
+    if (e.act == SRMI_ACT_RELU) s = 0.f;
+    else if (e.act == SRMI_ACT_LRELU) s = e.act_param;
+    else if (e.act == SRMI_ACT_PRELU) s = e.alpha[0];
+    s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, s)));
+    return (s >= 0.f && s <= 1.f) ? 1 : 2;
+}
 
 constexpr int C64_MAX_CHUNKS = 16;                       // Cout <= 1024
 constexpr int C64_PAR_BYTES = C64_MAX_CHUNKS * 3 * 64 * 4;  // per chunk: scale[64] | shift[64] | slope[64]
@@ -149,8 +169,8 @@ __device__ __forceinline__ void c64_epilogue(const f32x4 (&acc)[PT][4], const fl
             }
         }
     }
-    // SLOPE = false: no activation (slope 1 everywhere, e.g. the second conv of a ResBlock) - skips the select
-    auto body = [&](auto SLOPE) {
+    // KIND (c64_slope_kind): 0 no activation (e.g. the second conv of a ResBlock), 1 max form, 2 compare + select
+    auto body = [&](auto KIND) {
 #pragma unroll
         for (int k = 0; k < PT; ++k) {
             u32x4 o0, o1;
@@ -161,7 +181,8 @@ __device__ __forceinline__ void c64_epilogue(const f32x4 (&acc)[PT][4], const fl
                     const int j = 2 * t + e;                     // channel pair of this lane's 16 values
                     const f32x2 a = {acc[k][t][2 * e], acc[k][t][2 * e + 1]};
                     f32x2 v;
-                    if constexpr (decltype(SLOPE)::value) v = slope_act2(a, sc[j], sh[j], sl[j]);
+                    if constexpr (decltype(KIND)::value == 2) v = slope_act2(a, sc[j], sh[j], sl[j]);
+                    else if constexpr (decltype(KIND)::value == 1) v = slope_act2_max(a, sc[j], sh[j], sl[j]);
                     else v = __builtin_elementwise_fma(a, sc[j], sh[j]);
                     if (have_res) {
                         const unsigned w = r[k][j >> 2][j & 3];
@@ -177,8 +198,10 @@ __device__ __forceinline__ void c64_epilogue(const f32x4 (&acc)[PT][4], const fl
             }
         }
     };
-    if (o.act == SRMI_ACT_NONE) body(std::false_type{});
-    else body(std::true_type{});
+    const int kind = c64_slope_kind(o);
+    if (kind == 0) body(std::integral_constant<int, 0>{});
+    else if (kind == 1) body(std::integral_constant<int, 1>{});
+    else body(std::integral_constant<int, 2>{});
 }
 
 // scheduling directive: NR groups of {1 LDS read, ~NM/NR MFMAs} (compile-time only, no code emitted)

@@ -117,35 +117,54 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_c64_kernel(C64Params p) {
 
     C64ParRegs pregs;
     c64_params_load(pregs, p.epi, p.nchunk, tid);
-    if (!(p.dbg & 1))
     // ---- stage the input halo tile: global (NHWC bf16) -> registers -> swizzled LDS ----------
-    // All loads are issued before the first is consumed (clamped address + select, no branches):
-    // one HBM/L2 round trip for the whole tile instead of one per 16-B chunk.
-    {
-        constexpr int NCH = (TH + 2) * (TW + 2) * 8;  // 16-B chunks
-        constexpr int NIT = (NCH + NTH - 1) / NTH;
-        const bf16_t* xin = p.x + (size_t)n * p.H * p.W * p.in_cs;
-        u32x4 v[NIT];
+    // All loads are issued before the first is consumed: one HBM/L2 round trip for the whole tile.  Row-oriented so
+    // that almost all index arithmetic is wave-uniform or an immediate: part A gives a thread one (column, 16-B chunk)
+    // and walks the rows, part B spreads the left-over columns.  Pixels outside the image are read through a buffer
+    // descriptor at an out-of-range offset: zeros without touching memory (the conv's zero padding), no select.
+    if (!(p.dbg & 1)) {
+        constexpr int XR = TH + 2, XC = TW + 2;
+        constexpr int CPT = NTH / 8;                  // columns per pass
+        constexpr int NA = XC / CPT, RB = XC - NA * CPT;
+        constexpr int NB = (XR * RB * 8 + NTH - 1) / NTH;
+        constexpr unsigned OOB_COL = 0x80000000u, OOB_ROW = 0x40000000u;   // image bytes <= 2^30 (checked on the host)
+        const unsigned img_bytes = (unsigned)p.H * p.W * p.in_cs * 2;
+        const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.x + (size_t)n * p.H * p.W * p.in_cs), 0, img_bytes, 0x00020000);
+        const unsigned row_bytes = (unsigned)p.W * p.in_cs * 2;
+        const int ch = tid & 7, c0 = tid >> 3;
+        u32x4 va[NA > 0 ? NA * XR : 1], vb[NB > 0 ? NB : 1];
+        unsigned la[NA > 0 ? NA : 1], lb[NB > 0 ? NB : 1];
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int idx = min(tid + it * NTH, NCH - 1);
-            const int pp = idx >> 3, ch = idx & 7;
-            const int row = pp / (TW + 2), col = pp - row * (TW + 2);
-            const int gy = min(max(y0 - 1 + row, 0), p.H - 1), gx = min(max(x0 - 1 + col, 0), p.W - 1);
-            v[it] = *(const u32x4*)(xin + ((size_t)gy * p.W + gx) * p.in_cs + ch * 8);
+        for (int g = 0; g < NA; ++g) {
+            const int col = g * CPT + c0, gx = x0 - 1 + col;
+            const unsigned coff = (gx >= 0 && gx < p.W) ? (unsigned)gx * p.in_cs * 2 + ch * 16 : OOB_COL;
+            la[g] = col * 128 + ((ch ^ ((col >> 1) & 7)) << 4);     // ROWP % 16 == 0: the swizzle key depends on the column only
+#pragma unroll
+            for (int row = 0; row < XR; ++row) {
+                const int gy = y0 - 1 + row;                               // wave-uniform
+                const unsigned roff = (gy >= 0 && gy < p.H) ? (unsigned)gy * row_bytes : OOB_ROW;
+                va[g * XR + row] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, coff + roff, 0, 0));
+            }
         }
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int idx = tid + it * NTH;
-            const int pp = idx >> 3, ch = idx & 7;
-            const int row = pp / (TW + 2), col = pp - row * (TW + 2);
+        for (int i = 0; i < NB; ++i) {
+            const int sidx = tid + i * NTH;
+            const int row = sidx / (RB * 8), rem = sidx - row * (RB * 8);
+            const int col = NA * CPT + (rem >> 3), chb = rem & 7;
             const int gy = y0 - 1 + row, gx = x0 - 1 + col;
-            const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-            u32x4 z = v[it];
-            if (!ok) z = (u32x4){0u, 0u, 0u, 0u};
-            const int P = row * ROWP + col;
-            if (idx < NCH) *(u32x4*)(lds + P * 128 + ((ch ^ ((P >> 1) & 7)) << 4)) = z;
+            const bool ok = sidx < XR * RB * 8 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            const unsigned off = ok ? (unsigned)gy * row_bytes + (unsigned)gx * p.in_cs * 2 + chb * 16 : OOB_COL;
+            vb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 0));
+            lb[i] = (row * ROWP + col) * 128 + ((chb ^ ((col >> 1) & 7)) << 4);
         }
+#pragma unroll
+        for (int g = 0; g < NA; ++g)
+#pragma unroll
+            for (int row = 0; row < XR; ++row) *(u32x4*)(lds + la[g] + row * (ROWP * 128)) = va[g * XR + row];
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            if (tid + i * NTH < XR * RB * 8) *(u32x4*)(lds + lb[i]) = vb[i];
     }
 
     // per-wave pixel tiles: tile index t = wave*PT + k -> (row, 16-col group)
@@ -271,6 +290,8 @@ bool c64_supported(const srmi_conv_desc& d) {
     if (d.act == SRMI_ACT_TANH || d.act == SRMI_ACT_SIGMOID) return false;
     const int in_cs = d.in_cstride ? d.in_cstride : d.Cin;
     if (in_cs % 8 != 0) return false;
+    // the staging addresses one image through a 32-bit buffer descriptor with two out-of-range markers
+    if ((unsigned long long)d.H * d.W * in_cs * 2 > (1ull << 30)) return false;
     const int Cf = d.Cout / (d.shuffle * d.shuffle);
     const int out_cs = d.out_cstride ? d.out_cstride : Cf;
     if (out_cs % 8 != 0 || d.out_coffset % 8 != 0) return false;

@@ -288,12 +288,12 @@ __global__ __launch_bounds__(NW * 64, WGPC) void resblock_c64_kernel(
         if (extra) {
             if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (SLOTS - 3) + NRES) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NRES) : "memory");
-        } else {
+        } else if (!(kdbg & (1 << 17))) {       // (timing experiment: no wait for the weights)
             if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (SLOTS - 3)) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __builtin_amdgcn_s_barrier();
-        if (S + SLOTS - 2 < NS) issue_slot(S + SLOTS - 2);
+        if (!(kdbg & (1 << 18))) __builtin_amdgcn_s_barrier();      // (timing experiment: no hand-off barrier)
+        if (S + SLOTS - 2 < NS && !(kdbg & (1 << 19))) issue_slot(S + SLOTS - 2);     // (timing experiment: no weight stream)
     };
     // LDS address of the fragments of K-step g
     auto frag = [&](int g) { return wring + ((g / KS) % SLOTS) * SLOT_BYTES + (g % KS) * RB_STEP_BYTES + lane * 16; };
@@ -382,7 +382,7 @@ __global__ __launch_bounds__(NW * 64, WGPC) void resblock_c64_kernel(
         // 4+q is 64 B further (q ^ 4 under the swizzle).  Lanes / tiles past the end of the T region were clamped to
         // its last pixel: they hold the same values and write them to the same place.
         // Two passes (channels 8q.., then 32+8q..): 24 parameter registers live at a time instead of 48.
-        if (!(kdbg & 16))
+        auto twrite = [&](auto KIND) {
 #pragma unroll
         for (int hi = 0; hi < 2; ++hi) {
             f32x2 sc[4], sh[4], sl[4];
@@ -408,12 +408,18 @@ __global__ __launch_bounds__(NW * 64, WGPC) void resblock_c64_kernel(
 #pragma unroll
                     for (int e = 0; e < 2; ++e) {
                         const int t = 2 * hi + v4;
-                        const f32x2 v = slope_act2((f32x2){acc[k][t][2 * e], acc[k][t][2 * e + 1]}, sc[2 * v4 + e],
-                                                   sh[2 * v4 + e], sl[2 * v4 + e]);
+                        const f32x2 a = {acc[k][t][2 * e], acc[k][t][2 * e + 1]};
+                        const f32x2 v = decltype(KIND)::value == 1 ? slope_act2_max(a, sc[2 * v4 + e], sh[2 * v4 + e], sl[2 * v4 + e])
+                                                                   : slope_act2(a, sc[2 * v4 + e], sh[2 * v4 + e], sl[2 * v4 + e]);
                         o[2 * v4 + e] = pack_bf2(v[0], v[1]) & keep;      // channels 32hi + 8q + 4v4 + 2e, +1
                     }
                 *(u32x4*)(lds + (boff1[k][0] ^ (hi << 6))) = o;           // chunk q (hi = 0) or 4+q
             }
+        }
+        };
+        if (!(kdbg & 16)) {
+            if (c64_slope_kind(V.epi1) <= 1 && !(kdbg & (1 << 20))) twrite(std::integral_constant<int, 1>{});      // (none: slope 1, max(z, z) = z)
+            else twrite(std::integral_constant<int, 2>{});
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();           // T complete

@@ -44,7 +44,7 @@ def _ref_fused(x_nchw, w, scale, shift, act, act_param, alpha, residual_nchw, st
     return z
 
 
-def _run_case(N, H, W, Cin, Cout, k, *, stride=1, act=L.ACT_NONE, act_param=0.0, alpha_pc=0, residual=False, r=1,
+def _run_case(N, H, W, Cin, Cout, k, *, stride=1, act=L.ACT_NONE, act_param=0.0, alpha_pc=0, alpha_val=None, residual=False, r=1,
               dcr=False, io=torch.float32, compute=L.COMPUTE_F32, in_layout=L.NHWC, out_layout=L.NHWC,
               in_cs=0, out_cs=0, out_co=0, res_cs=0, seed=0):
     g = _rng(seed)
@@ -53,6 +53,8 @@ def _run_case(N, H, W, Cin, Cout, k, *, stride=1, act=L.ACT_NONE, act_param=0.0,
     scale = torch.from_numpy(g.uniform(0.5, 1.5, Cout).astype(np.float32))
     shift = torch.from_numpy(g.uniform(-0.3, 0.3, Cout).astype(np.float32))
     alpha = torch.from_numpy(g.uniform(0.05, 0.4, Cout if alpha_pc else 1).astype(np.float32))
+    if alpha_val is not None:            # a scalar slope outside [0, 1]: the compare + select form, not max(z, z*slope)
+        alpha = torch.tensor([alpha_val], dtype=torch.float32)
     bf = io == torch.bfloat16
     if bf:                       # the kernel sees bf16-rounded activations / weights: so does the reference
         x = x.bfloat16().float()
@@ -174,6 +176,9 @@ def test_generic_kernel_bf16_storage(case):
     dict(N=1, H=8, W=8, Cout=64, act=L.ACT_LRELU, act_param=0.2, in_cs=160, out_cs=160, out_co=64),  # concat slices
     dict(N=1, H=15, W=120, Cout=64, act=L.ACT_PRELU, residual=True),          # 8 x 64 tile (fewer rounds), ragged
     dict(N=1, H=16, W=128, Cout=256, act=L.ACT_PRELU, r=2),                   # 8 x 64 tile + PixelShuffle store
+    dict(N=1, H=9, W=20, Cout=64, act=L.ACT_PRELU, alpha_val=-0.5),           # learned slope outside [0, 1]
+    dict(N=1, H=9, W=20, Cout=64, act=L.ACT_PRELU, alpha_val=1.5, residual=True),
+    dict(N=1, H=9, W=20, Cout=64, act=L.ACT_LRELU, act_param=1.25),
 ])
 def test_c64_bf16_kernel(case):
     name = _run_case(Cin=64, k=3, io=torch.bfloat16, compute=L.COMPUTE_BF16, **case)
@@ -271,6 +276,8 @@ def test_k9c3_kernel(case):
     dict(N=1, H=24, W=192),
     dict(N=1, H=13, W=100, other_res=True),     # the residual is NOT the block input: read from memory, not from the LDS tile
     dict(N=2, H=11, W=13, other_res=True),
+    dict(N=1, H=13, W=100, alpha=-0.75),        # conv1 slope outside [0, 1]: compare + select form of the T write-back
+    dict(N=1, H=13, W=100, alpha=1.0),
 ])
 def test_fused_resblock_kernel(case):
     """ResBlock in one launch == conv-affine-PReLU -> (bf16 T) -> conv-affine -> +x, the intermediate rounded to
@@ -285,7 +292,7 @@ def test_fused_resblock_kernel(case):
         ws.append(torch.from_numpy((g.standard_normal((64, 64, 3, 3)) / 24.0).astype(np.float32)).bfloat16().float())
         scs.append(torch.from_numpy(g.uniform(0.5, 1.5, 64).astype(np.float32)))
         shs.append(torch.from_numpy(g.uniform(-0.3, 0.3, 64).astype(np.float32)))
-    alpha = torch.tensor([0.25])
+    alpha = torch.tensor([case.get("alpha", 0.25)])
     res = x
     if case.get("other_res"):
         res = torch.from_numpy(g.uniform(-1, 1, (N, 64, H, W)).astype(np.float32)).bfloat16().float()
