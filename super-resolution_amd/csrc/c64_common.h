@@ -170,7 +170,8 @@ __device__ __forceinline__ void c64_epilogue(const f32x4 (&acc)[PT][4], const fl
         }
     }
     // KIND (c64_slope_kind): 0 no activation (e.g. the second conv of a ResBlock), 1 max form, 2 compare + select
-    auto body = [&](auto KIND) {
+    // RES: a residual is added (compile-time per variant: as a run-time flag hipcc turns the add into 40 selects per tile)
+    auto body = [&](auto KIND, auto RES) {
 #pragma unroll
         for (int k = 0; k < PT; ++k) {
             u32x4 o0, o1;
@@ -184,7 +185,7 @@ __device__ __forceinline__ void c64_epilogue(const f32x4 (&acc)[PT][4], const fl
                     if constexpr (decltype(KIND)::value == 2) v = slope_act2(a, sc[j], sh[j], sl[j]);
                     else if constexpr (decltype(KIND)::value == 1) v = slope_act2_max(a, sc[j], sh[j], sl[j]);
                     else v = __builtin_elementwise_fma(a, sc[j], sh[j]);
-                    if (have_res) {
+                    if constexpr (decltype(RES)::value) {
                         const unsigned w = r[k][j >> 2][j & 3];
                         v += (f32x2){__builtin_bit_cast(float, w << 16), __builtin_bit_cast(float, w & 0xffff0000u)};
                     }
@@ -199,9 +200,15 @@ __device__ __forceinline__ void c64_epilogue(const f32x4 (&acc)[PT][4], const fl
         }
     };
     const int kind = c64_slope_kind(o);
-    if (kind == 0) body(std::integral_constant<int, 0>{});
-    else if (kind == 1) body(std::integral_constant<int, 1>{});
-    else body(std::integral_constant<int, 2>{});
+    if (have_res) {
+        if (kind == 0) body(std::integral_constant<int, 0>{}, std::true_type{});
+        else if (kind == 1) body(std::integral_constant<int, 1>{}, std::true_type{});
+        else body(std::integral_constant<int, 2>{}, std::true_type{});
+    } else {
+        if (kind == 0) body(std::integral_constant<int, 0>{}, std::false_type{});
+        else if (kind == 1) body(std::integral_constant<int, 1>{}, std::false_type{});
+        else body(std::integral_constant<int, 2>{}, std::false_type{});
+    }
 }
 
 // scheduling directive: NR groups of {1 LDS read, ~NM/NR MFMAs} (compile-time only, no code emitted)

@@ -333,6 +333,7 @@ int c64_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     p.epi.act = d.act; p.epi.act_param = d.act_param; p.epi.alpha_pc = d.alpha_per_channel;
     p.N = d.N; p.H = d.H; p.W = d.W; p.nchunk = d.Cout / 64; p.in_cs = g.in_cs;
     p.dbg = dbg_flags();
+    if (p.dbg & 1024) p.epi.H = 0;      // timing experiment: epilogue arithmetic only (every pixel fails the bounds check: no loads, no stores)
     if (d.N == 0 || d.H == 0 || d.W == 0) return SRMI_OK;
     // tile choice (pick_tile3x3): 6 x 96 (9 pixel tiles per wave), 8 x 64 (8 per wave) or 4 x 32 (2 per wave),
     // whichever wastes the fewest workgroup-rounds on ragged edges and a partly filled last round.
