@@ -32,6 +32,7 @@ struct C64Params {
     C64Epi epi;   // scale/shift/alpha/residual/output, store mode (0 plain, 1 PixelShuffle(2) CRD, 2 depth_to_space(2) DCR)
     int N, H, W, nchunk, in_cs;
     int tiles_x, tiles_y;
+    int stagger, first_round;   // start-time stagger of the first round's workgroups (0: none)
     int dbg;  // ablation switches (SRMI_DBG env, investigation only): 1 skip staging, 2 skip K loop, 4 skip epilogue
 };
 
@@ -42,21 +43,28 @@ constexpr int C64_TAP_BYTES = 8192;   // 2 k-steps x 4 channel tiles x 64 lanes 
 
 // NW = waves per workgroup: 4 (one per SIMD, 512 registers each) or 8 (two per SIMD, 256 each: the second wave of a
 // SIMD fills the first one's LDS / barrier / epilogue bubbles; same tile and LDS, half the pixel tiles per wave).
-template <int TH, int TWT, int NW>
-__global__ __launch_bounds__(NW * 64, 1) void conv_c64_kernel(C64Params p) {
+// SLOTS = ring depth (taps), WGPC = workgroups per CU the register budget is cut for, PITCH = LDS row pitch granule
+// (16: padded, the swizzle key can be taken from the pixel index; 2: unpadded, column-keyed), MAXCH = output chunks
+// the parameter area holds.  <6, 3, 4, 3, 2, 2, 4>: a 6 x 48 tile in 77 KiB of LDS and 256 registers - TWO workgroups
+// per CU, so that one's staging / epilogue / store-acknowledge waits run under the other's MFMA phases (multi-round
+// launches, where the two drift out of phase).
+template <int TH, int TWT, int NW, int SLOTS = C64_WRING, int WGPC = 1, int PITCH = 16, int MAXCH = C64_MAX_CHUNKS>
+__global__ __launch_bounds__(NW * 64, WGPC) void conv_c64_kernel(C64Params p) {
     constexpr int NTH = NW * 64;
     constexpr int TW = TWT * 16;
     constexpr int NPT = TH * TWT;
     constexpr int PT = (NPT + NW - 1) / NW;            // waves past the end recompute the last tile and store nothing
     constexpr int WAVE_BYTES = C64_TAP_BYTES / NW;     // each wave moves 1/NW of every tap
     constexpr int NDMA = WAVE_BYTES / 1024;            // LDS-DMA instructions per wave and tap (2 or 1)
-    constexpr int ROWP = (TW + 2 + 15) / 16 * 16;  // LDS row pitch in pixels (multiple of 16: swizzle independent of dy)
+    constexpr int ROWP = (TW + 2 + PITCH - 1) / PITCH * PITCH;  // LDS row pitch in pixels: even, so a row starts on a 256-B bank row
+    static_assert(ROWP % 2 == 0, "pixel pairs must not straddle rows");
+    auto swz = [](int P, int col) { return ROWP % 16 == 0 ? (P >> 1) & 7 : (col >> 1) & 7; };   // swizzle key: the same for every row
     constexpr int IN_BYTES = (TH + 2) * ROWP * 128;
     // ONE shared array (input tile | weight ring): a second __shared__ object next to an LDS-DMA
     // target makes hipcc drain vmcnt before every ds_read (cdna guide, "three .s-level traps").
-    __shared__ __attribute__((aligned(16))) unsigned char lds[IN_BYTES + C64_WRING * C64_TAP_BYTES + C64_PAR_BYTES];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[IN_BYTES + SLOTS * C64_TAP_BYTES + MAXCH * 768];
     unsigned char* const wring = lds + IN_BYTES;
-    float* const par = (float*)(lds + IN_BYTES + C64_WRING * C64_TAP_BYTES);
+    float* const par = (float*)(lds + IN_BYTES + SLOTS * C64_TAP_BYTES);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -66,6 +74,15 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_c64_kernel(C64Params p) {
 
     // XCD-aware tile order: consecutive workgroup ids go round-robin to the 8 XCDs (one L2 each), so give each
     // XCD a CONTIGUOUS run of tiles - vertically adjacent tiles then share their halo rows through one L2.
+    if (p.stagger > 0) {
+        // Timing experiment (SRMI_STAGGER=n, off by default): hold the workgroups of the first round back by 0 .. n-1
+        // micro-delays (~1.1 us each, hashed from the workgroup id) so that the CUs do not stage, compute and store in
+        // lockstep across the chip.  Measured: no gain on the 4-round up conv (168.7 vs 172 us at n = 8).
+        if (blockIdx.x < (unsigned)p.first_round) {
+            const int dly = (int)(((blockIdx.x * 2654435761u) >> 16) % (unsigned)p.stagger);
+            for (int i = 0; i < dly; ++i) __builtin_amdgcn_s_sleep(42);
+        }
+    }
     int b = blockIdx.x;
     if ((gridDim.x & 7) == 0 && !(p.dbg & 32)) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
     const int tx = b % p.tiles_x; b /= p.tiles_x;
@@ -84,7 +101,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_c64_kernel(C64Params p) {
     auto issue_tap = [&](int g) {
         const unsigned char* src = wsrc + (size_t)g * C64_TAP_BYTES;
         const unsigned dst = __builtin_amdgcn_readfirstlane(
-            wring_lds + (unsigned)((g & (C64_WRING - 1)) * C64_TAP_BYTES + wave * WAVE_BYTES));
+            wring_lds + (unsigned)((g % SLOTS) * C64_TAP_BYTES + wave * WAVE_BYTES));
         unsigned keep;
         if constexpr (NDMA == 2) {
             asm volatile(
@@ -111,9 +128,9 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_c64_kernel(C64Params p) {
                 : "memory");
         }
     };
-    issue_tap(0);
-    if (ntap > 1) issue_tap(1);
-    if (ntap > 2) issue_tap(2);
+#pragma unroll
+    for (int g = 0; g < SLOTS - 1; ++g)
+        if (g < ntap) issue_tap(g);
 
     C64ParRegs pregs;
     c64_params_load(pregs, p.epi, p.nchunk, tid);
@@ -188,8 +205,9 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_c64_kernel(C64Params p) {
     for (int k = 0; k < PT; ++k)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
-            const int P = prow[k] * ROWP + pcol[k] + pl + dx;
-            boff[k][dx] = P * 128 + ((q ^ ((P >> 1) & 7)) << 4);
+            const int col = pcol[k] + pl + dx;
+            const int P = prow[k] * ROWP + col;
+            boff[k][dx] = P * 128 + ((q ^ swz(P, col)) << 4);
         }
 #pragma unroll
     for (int k = 0; k < PT; ++k)
@@ -209,7 +227,7 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_c64_kernel(C64Params p) {
         // tap g so that the first fragments of the next tap can be prefetched like any others.
         bf16x8 afr[2][4], bfr[2][PT];
         {
-            const unsigned char* wslot = wring + ((s * 9) & (C64_WRING - 1)) * C64_TAP_BYTES + lane * 16;
+            const unsigned char* wslot = wring + ((s * 9) % SLOTS) * C64_TAP_BYTES + lane * 16;
 #pragma unroll
             for (int t = 0; t < 4; ++t) afr[0][t] = *(const bf16x8*)(wslot + t * 1024);
 #pragma unroll
@@ -223,16 +241,17 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_c64_kernel(C64Params p) {
             if (half == 1) {
                 // tap g+1 landed: own copies by counted vmcnt (tap g+2 stays in flight), the other waves'
                 // by the barrier, which also retires every wave's reads of tap g-1 -> its slot is free.
-                if (g + 2 < ntap) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+                // (taps g+1 .. g+SLOTS-2 are in flight; all but g+1 may stay so)
+                if (SLOTS >= 4 && g + 2 < ntap) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (SLOTS - 3)) : "memory");
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
-                if (g + 3 < ntap) issue_tap(g + 3);
+                if (g + SLOTS - 1 < ntap) issue_tap(g + SLOTS - 1);
             }
             if (j + 1 < 18) {
                 const int tapn = (j + 1) >> 1, halfn = (j + 1) & 1;
                 const int dyn = tapn / 3, dxn = tapn - 3 * dyn;
                 const unsigned char* wslot =
-                    wring + ((s * 9 + tapn) & (C64_WRING - 1)) * C64_TAP_BYTES + lane * 16 + halfn * 4096;
+                    wring + ((s * 9 + tapn) % SLOTS) * C64_TAP_BYTES + lane * 16 + halfn * 4096;
 #pragma unroll
                 for (int t = 0; t < 4; ++t) afr[(j + 1) & 1][t] = *(const bf16x8*)(wslot + t * 1024);
 #pragma unroll
@@ -343,7 +362,17 @@ int c64_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     const long long nb = (long long)d.N * p.tiles_x * p.tiles_y;
     if (nb > 0x7fffffffLL) { set_error("c64_bf16: grid too large"); return SRMI_EINVAL; }
     const bool w4 = (p.dbg & 256) != 0;    // ablation: the 4-wave variants
-    if (tile == 0 && w4) hipLaunchKernelGGL((conv_c64_kernel<6, 6, 4>), dim3((unsigned)nb), dim3(256), 0, s, p);
+    p.stagger = 0; p.first_round = 256;
+    { const char* e = getenv("SRMI_STAGGER"); if (e) p.stagger = atoi(e); }
+    // Two workgroups per CU (6 x 48 tiles) once the launch has several rounds of them: they drift out of phase and
+    // hide each other's staging, epilogue and store waits.  (One round runs in lockstep and gains nothing.)
+    const long long nb2 = (long long)d.N * ((d.W + 47) / 48) * ((d.H + 5) / 6);
+    const bool two = tile == 0 && p.nchunk <= 4 && !w4 && ((p.dbg & (1 << 21)) ? false : ((p.dbg & (1 << 22)) ? true : nb2 >= 1024));
+    if (two) {
+        p.first_round = 512;
+        p.tiles_x = (d.W + 47) / 48; p.tiles_y = (d.H + 5) / 6;
+        hipLaunchKernelGGL((conv_c64_kernel<6, 3, 4, 3, 2, 2, 4>), dim3((unsigned)nb2), dim3(256), 0, s, p);
+    } else if (tile == 0 && w4) hipLaunchKernelGGL((conv_c64_kernel<6, 6, 4>), dim3((unsigned)nb), dim3(256), 0, s, p);
     else if (tile == 0) hipLaunchKernelGGL((conv_c64_kernel<6, 6, 8>), dim3((unsigned)nb), dim3(512), 0, s, p);
     else if (tile == 1 && w4) hipLaunchKernelGGL((conv_c64_kernel<8, 4, 4>), dim3((unsigned)nb), dim3(256), 0, s, p);
     else if (tile == 1) hipLaunchKernelGGL((conv_c64_kernel<8, 4, 8>), dim3((unsigned)nb), dim3(512), 0, s, p);

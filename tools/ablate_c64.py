@@ -1,7 +1,7 @@
 """Phase ablation of the Cin = 64 conv kernel (timing only; SRMI_DBG bits: 1 no staging, 2 no K loop, 4 no epilogue)."""
 import os, sys, json, subprocess
-for dbg in [0, 1024, 4, 1, 0]:
-    env = dict(os.environ, SRMI_DBG=str(dbg))
+for dbg in [0, 1024, 4, 1, 2, 6, 7, 0]:
+    env = dict(os.environ, SRMI_DBG=str(dbg | int(os.environ.get('BASE_DBG', '0'))))
     out = subprocess.run([sys.executable, "bench.py", "--steps", "20", "--warmup", "5", "--no-cpu-baseline"], env=env,
                          capture_output=True, text=True).stdout
     r = json.loads(out.strip().splitlines()[-1])
