@@ -268,10 +268,11 @@ int srmi_conv2d_fwd_seq(const srmi_conv_args* a, int32_t n, void* stream) {
         if ((a[i].flags & SRMI_CONV_FUSE_NEXT) && i + 1 < n && can_fuse_pair(a + i, a + i + 1)) {
             // a run of fusable pairs that feed each other goes out as ONE persistent launch when every tile fits the GPU
             int32_t pairs = 1;
-            while (i + 2 * pairs + 1 < n && (a[i + 2 * pairs].flags & SRMI_CONV_FUSE_NEXT) &&
+            if (!resblock_chain_on()) pairs = 0;      // chain disabled: skip the scan
+            while (pairs && i + 2 * pairs + 1 < n && (a[i + 2 * pairs].flags & SRMI_CONV_FUSE_NEXT) &&
                    can_fuse_pair(a + i + 2 * pairs, a + i + 2 * pairs + 1))
                 ++pairs;
-            const int m = resblock_chain_length(a + i, pairs);
+            const int m = pairs ? resblock_chain_length(a + i, pairs) : 0;
             if (m >= 2) {
                 int rc = resblock_chain_launch(a + i, m, (hipStream_t)stream);
                 if (rc) return rc;

@@ -116,6 +116,7 @@ int resblock_chain_length(const srmi_conv_args* a, int npairs);      // 0: not a
 int resblock_chain_launch(const srmi_conv_args* a, int nblocks, hipStream_t s);
 int resblock_chain_timeouts(unsigned* count);
 int resblock_chain_enable(int on);
+bool resblock_chain_on();
 int resblock_chain_trace(unsigned long long* out, int n);
 
 }  // namespace srmi

@@ -690,6 +690,8 @@ ChainDev* chain_dev() {
 // How many of the `npairs` fusable (conv1, conv2) pairs starting at a[0] can run as ONE persistent launch (0: use the
 // per-block launches).  Conditions: same shape, every block's residual is its own input, block i+1 reads what block i
 // wrote, dense 64-channel tensors, the big tile, and every tile resident at once.
+bool resblock_chain_on() { return chain_enabled() != 0; }
+
 int resblock_chain_length(const srmi_conv_args* a, int npairs) {
     if (npairs < 2 || !chain_enabled()) return 0;
     const srmi_conv_desc& d = a[0].d;
