@@ -36,7 +36,7 @@ struct ThinParams {
     int out_nchw, out_bf16;
     int strips, bands, band_rows;
     unsigned y_bytes;
-    int dbg;   // ablation (SRMI_DBG, investigation only): 2 skip MFMAs, 4 skip activation math
+    int dbg;   // ablation (SRMI_DBG, investigation only): 2 skip MFMAs, 4 skip activation math, 8 skip the output stores
 };
 
 constexpr int THIN_NS = 8;               // ring slots (input rows): 7 rows = 59 KB in flight per workgroup
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void conv_thin_kernel(ThinParams p) {
         // output row o = r - 2 is complete (its tap row 2 was just added): acc[(R3 - 2 + 3) % 3]
         const int o = r - 2;
         const int oy = y0 + o;
-        const bool ok = lane_out && o >= 0 && o < nrows;
+        const bool ok = lane_out && o >= 0 && o < nrows && !(p.dbg & 8);     // (dbg 8: timing experiment, no output stores)
         const f32x4 a = acc[(R3 + 1) % 3];
         // byte offset of (channel 0, oy, ox); tensors are < 4 GiB (thin_supported), so 32-bit arithmetic
         const unsigned off0 = p.out_nchw ? (unsigned)(((n * p.Cout) * p.H + oy) * p.W + ox) * esz
