@@ -9,7 +9,7 @@
 //   LDS (one array, 157 KiB for the 6 x 96 tile):
 //     [ x halo tile (TH+4) x (TW+4) px, later overwritten by T (TH+2) x (TW+2) px | weight ring | params ]
 //   phase 1  conv1 on the (TH+2) x (TW+2) T region, FLATTENED into 16-pixel MFMA tiles (49 tiles for
-//            8 x 98 pixels, 13 per wave) so the halo ring costs 1.44x, not 1.56x, of a tile's MFMAs;
+//            8 x 98 pixels, 7 per wave with 8 waves) so the halo ring costs 1.36x, not 1.56x, of a tile's MFMAs;
 //   phase 2  barrier; T = act(affine1(acc)) -> bf16, zero outside the image (conv2's zero padding),
 //            written over the x tile in the same swizzled layout; barrier;
 //   phase 3  conv2 from T exactly like conv_c64_kernel; epilogue adds x and stores.  With 8 waves (5 pixel tiles
