@@ -1,0 +1,73 @@
+"""Seeded shape fuzz of the LDS-tiled bf16 kernels: ragged tiles of every variant (6x96, 8x64, 4x32, the 6x48
+two-workgroup tile), channel slices, all store modes - each case against the CPU f64 restatement (one output
+rounding), and the fused ResBlock bit-for-bit against its two-launch form."""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import test_kernels_gpu as K
+
+L = importlib.import_module("super-resolution_amd.srmi._lib")
+pytestmark = pytest.mark.gpu
+
+
+def _c64_cases(n, seed):
+    g = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        kind = i % 5
+        H = int(g.integers(1, 40)); W = int(g.integers(1, 200))
+        N = int(g.integers(1, 4))
+        case = dict(N=N, H=H, W=W)
+        if kind == 0:
+            case.update(Cout=64, act=L.ACT_PRELU, residual=bool(g.integers(0, 2)))
+        elif kind == 1:
+            case.update(Cout=256, act=L.ACT_PRELU, r=2, dcr=bool(g.integers(0, 2)), alpha_pc=int(g.integers(0, 2)))
+        elif kind == 2:
+            case.update(Cout=128, act=L.ACT_LRELU, act_param=float(g.uniform(0.0, 0.3)))
+        elif kind == 3:
+            case.update(Cout=64, act=L.ACT_NONE, residual=True, in_cs=160, out_cs=160, out_co=int(g.integers(0, 13)) * 8)
+        else:
+            case.update(Cout=64, act=L.ACT_RELU, in_cs=int(g.integers(8, 21)) * 8)
+        out.append(case)
+    # shapes that select the two-workgroup 6x48 tile (>= 1024 of them) and the 8x64 tile, ragged
+    out.append(dict(N=2, H=190, W=187, Cout=256, act=L.ACT_PRELU, r=2))
+    out.append(dict(N=1, H=250, W=250, Cout=64, act=L.ACT_PRELU, residual=True))
+    return out
+
+
+@pytest.mark.parametrize("case", _c64_cases(30, seed=2024))
+def test_c64_fuzz(case):
+    assert K._run_case(Cin=64, k=3, io=torch.bfloat16, compute=L.COMPUTE_BF16, **case) == "c64_bf16"
+
+
+def _resblock_cases(n, seed):
+    g = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        out.append(dict(N=int(g.integers(1, 4)), H=int(g.integers(1, 30)), W=int(g.integers(1, 210)),
+                        other_res=bool(i % 4 == 3), alpha=float(g.choice([0.25, 0.0, 1.0, -0.3]))))
+    return out
+
+
+@pytest.mark.parametrize("case", _resblock_cases(16, seed=77))
+def test_resblock_fuzz(case):
+    K.test_fused_resblock_kernel(case)
+
+
+def _chain_cases(n, seed):
+    g = np.random.default_rng(seed)
+    out = []
+    while len(out) < n:
+        N, H, W = int(g.integers(1, 5)), int(g.integers(6, 60)), int(g.integers(65, 300))
+        if N * ((H + 5) // 6) * ((W + 95) // 96) <= 256:        # every tile resident at once, or the chain is not used
+            out.append(dict(N=N, H=H, W=W, nblk=int(g.integers(2, 7))))
+    return out
+
+
+@pytest.mark.parametrize("case", _chain_cases(8, seed=5))
+def test_chain_fuzz(case):
+    import test_chain_gpu as Cg
+    Cg.test_chain_matches_per_block_launches(case)
