@@ -71,3 +71,47 @@ def _chain_cases(n, seed):
 def test_chain_fuzz(case):
     import test_chain_gpu as Cg
     Cg.test_chain_matches_per_block_launches(case)
+
+
+def _cin_cases(n, seed):
+    g = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        Cin = int(g.choice([32, 96, 128, 160, 192, 256]))
+        Cout = int(g.choice([32, 64, 96, 128]))
+        case = dict(N=int(g.integers(1, 3)), H=int(g.integers(1, 30)), W=int(g.integers(1, 150)), Cin=Cin, Cout=Cout,
+                    act=int(g.choice([L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU, L.ACT_PRELU])), act_param=0.2)
+        if i % 3 == 0:
+            case.update(in_cs=Cin + 32, out_cs=Cout + 64, out_co=int(g.integers(0, 9)) * 8)
+        if i % 4 == 1:
+            case.update(residual=True)
+        out.append(case)
+    return out
+
+
+@pytest.mark.parametrize("case", _cin_cases(16, seed=9))
+def test_cin_fuzz(case):
+    assert K._run_case(k=3, io=torch.bfloat16, compute=L.COMPUTE_BF16, **case) == "cin_bf16"
+
+
+def _thin_cases(n, seed):
+    g = np.random.default_rng(seed)
+    return [dict(N=int(g.integers(1, 3)), H=int(g.integers(1, 60)), W=int(g.integers(1, 200)), Cout=int(g.integers(1, 5)),
+                 act=int(g.choice([L.ACT_TANH, L.ACT_NONE, L.ACT_SIGMOID])), out_layout=int(g.choice([L.NCHW, L.NHWC])),
+                 in_cs=int(g.choice([0, 96, 160]))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("case", _thin_cases(12, seed=10))
+def test_thin_fuzz(case):
+    K.test_c64_thin_kernel(case)
+
+
+def _k9_cases(n, seed):
+    g = np.random.default_rng(seed)
+    return [dict(N=int(g.integers(1, 3)), H=int(g.integers(1, 40)), W=int(g.integers(1, 150)),
+                 in_layout=int(g.choice([L.NCHW, L.NHWC])), Cin=int(g.choice([1, 3]))) for _ in range(n)]
+
+
+@pytest.mark.parametrize("case", _k9_cases(10, seed=11))
+def test_k9c3_fuzz(case):
+    K.test_k9c3_kernel(case)
