@@ -179,6 +179,29 @@ int srmi_u8hwc_to_f32nchw(const uint8_t* src, float* dst, int32_t N, int32_t H, 
 int srmi_f32nchw_to_u8hwc(const float* src, uint8_t* dst, int32_t N, int32_t H, int32_t W, int32_t C, int32_t clip,
                           void* stream);
 
+/* Training data pipeline on the device: `crop` + `augmentation` + normalisation + HWC->CHW of
+ * `mydata.__getitem__` (P/dataset.py:27-49, :81-132) for a whole batch in one launch.  The dataset lives in device
+ * memory as two packed uint8 HWC buffers (LR images, GT images; GT = scale x LR in both dimensions); `items` is a
+ * DEVICE array of B descriptors that the host fills from the same random draws the reference makes
+ * (P/dataset.py:92-93: ix, iy; :111-113: hor_flip, ver_flip, rot, applied in that order: fliplr, flipud, transpose).
+ * Outputs: lr_out [B, C, patch, patch], gt_out [B, C, scale*patch, scale*patch], f32 NCHW, `v / 127.5 - 1`
+ * evaluated in f32 when f32_arith != 0 (the in-memory path, P/dataset.py:33-34 + :40-41) or in f64 and rounded once
+ * (the from-disk path, :37-41).  Bit-exact with the reference's numpy expressions. */
+typedef struct srmi_crop_item {
+    int64_t lr_offset;   /* byte offset of the LR image in lr_pack */
+    int64_t gt_offset;   /* byte offset of the GT image in gt_pack */
+    int32_t lr_h, lr_w;  /* LR image size; the GT image is scale*lr_h x scale*lr_w */
+    int32_t iy, ix;      /* top-left corner of the LR patch */
+    int32_t flags;       /* SRMI_AUG_* */
+    int32_t reserved;    /* must be 0 */
+} srmi_crop_item;
+#define SRMI_AUG_HFLIP 1
+#define SRMI_AUG_VFLIP 2
+#define SRMI_AUG_TRANSPOSE 4
+int srmi_crop_augment_u8(const uint8_t* lr_pack, const uint8_t* gt_pack, const srmi_crop_item* items, int32_t B,
+                         int32_t patch, int32_t scale, int32_t C, int32_t f32_arith, float* lr_out, float* gt_out,
+                         void* stream);
+
 /* ---- losses and metrics (HBM-bound reductions) ------------------------------------------------
  * All results are written to DEVICE memory (no host synchronisation).  `ws` is a caller-owned device
  * workspace of at least SRMI_REDUCE_WS_BYTES bytes, 8-byte aligned; it holds the per-workgroup f64

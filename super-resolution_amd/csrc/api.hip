@@ -67,6 +67,8 @@ int wgrad_launch(const srmi_conv_desc& d, const ConvGeom& g, const float* x, con
 
 int u8_to_f32(const unsigned char* src, float* dst, int N, int H, int W, int C, hipStream_t s);
 int f32_to_u8(const float* src, unsigned char* dst, int N, int H, int W, int C, int clip, hipStream_t s);
+int crop_augment(const unsigned char* lr_pack, const unsigned char* gt_pack, const srmi_crop_item* items, int B, int patch,
+                 int scale, int C, int f32_arith, float* lr_out, float* gt_out, hipStream_t s);
 
 static bool is_dtype(int v) { return v == SRMI_F32 || v == SRMI_BF16; }
 static bool is_layout(int v) { return v == SRMI_NHWC || v == SRMI_NCHW; }
@@ -292,6 +294,16 @@ int srmi_conv2d_fwd_seq(const srmi_conv_args* a, int32_t n, void* stream) {
 
 // investigation only, not declared in srmi.h: phase time stamps of the last traced chain launch (SRMI_DBG bit 16384)
 int srmi_debug_chain_trace(unsigned long long* out, int n) { return resblock_chain_trace(out, n); }
+
+int srmi_crop_augment_u8(const uint8_t* lr_pack, const uint8_t* gt_pack, const srmi_crop_item* items, int32_t B,
+                         int32_t patch, int32_t scale, int32_t C, int32_t f32_arith, float* lr_out, float* gt_out,
+                         void* stream) {
+    if (B < 0 || patch < 0 || scale < 1 || C < 1) { set_error("crop_augment: bad arguments"); return SRMI_EINVAL; }
+    if ((size_t)B * patch == 0) return SRMI_OK;
+    if (!lr_pack || !gt_pack || !items || !lr_out || !gt_out) { set_error("crop_augment: NULL buffer"); return SRMI_EINVAL; }
+    if ((long long)patch * scale > 0x7fff) { set_error("crop_augment: patch too large"); return SRMI_EINVAL; }
+    return crop_augment(lr_pack, gt_pack, items, B, patch, scale, C, f32_arith, lr_out, gt_out, (hipStream_t)stream);
+}
 
 int srmi_chain_enable(int32_t on) {
     return resblock_chain_enable(on);

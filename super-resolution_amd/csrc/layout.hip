@@ -106,6 +106,54 @@ int f32_to_u8(const float* src, unsigned char* dst, int N, int H, int W, int C, 
     return hip_check(hipGetLastError(), "f32nchw_to_u8hwc_kernel");
 }
 
+// crop + augmentation + normalisation + HWC->CHW of one training batch (P/dataset.py:27-49, :81-132).
+// Output element (b, c, oy, ox) of the final patch = T(V(H(patch))): undo the transpose, then the vertical, then the
+// horizontal flip to find the source pixel.  One launch covers the LR and the GT outputs (GT elements first).
+__global__ void crop_augment_kernel(const unsigned char* __restrict__ lr_pack, const unsigned char* __restrict__ gt_pack,
+                                    const srmi_crop_item* __restrict__ items, int C, int patch, int scale, int f32_arith,
+                                    float* __restrict__ lr_out, float* __restrict__ gt_out, size_t n_gt, size_t total) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (size_t)gridDim.x * blockDim.x) {
+        const bool is_gt = idx < n_gt;
+        size_t e = is_gt ? idx : idx - n_gt;
+        const int P = is_gt ? patch * scale : patch;
+        const int ox = (int)(e % P); e /= P;
+        const int oy = (int)(e % P); e /= P;
+        const int c = (int)(e % C);
+        const int b = (int)(e / C);
+        const srmi_crop_item it = items[b];
+        int y = oy, x = ox;
+        if (it.flags & SRMI_AUG_TRANSPOSE) { y = ox; x = oy; }
+        if (it.flags & SRMI_AUG_VFLIP) y = P - 1 - y;
+        if (it.flags & SRMI_AUG_HFLIP) x = P - 1 - x;
+        const int s = is_gt ? scale : 1;
+        const size_t W = (size_t)it.lr_w * s;
+        const unsigned char* img = is_gt ? gt_pack + it.gt_offset : lr_pack + it.lr_offset;
+        const unsigned char u = img[(((size_t)it.iy * s + y) * W + (size_t)it.ix * s + x) * C + c];
+        float v;
+        if (f32_arith) {
+            v = (float)u / 127.5f;      // two f32 roundings, like numpy on a float32 array
+            v = v - 1.0f;
+        } else {
+            v = (float)((double)u / 127.5 - 1.0);
+        }
+        (is_gt ? gt_out : lr_out)[is_gt ? idx : idx - n_gt] = v;
+    }
+}
+
+int crop_augment(const unsigned char* lr_pack, const unsigned char* gt_pack, const srmi_crop_item* items, int B, int patch,
+                 int scale, int C, int f32_arith, float* lr_out, float* gt_out, hipStream_t s) {
+    const size_t n_lr = (size_t)B * C * patch * patch;
+    const size_t n_gt = n_lr * scale * scale;
+    const size_t total = n_lr + n_gt;
+    if (total == 0) return SRMI_OK;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(crop_augment_kernel, dim3((unsigned)blocks), dim3(256), 0, s, lr_pack, gt_pack, items, C, patch, scale,
+                       f32_arith, lr_out, gt_out, n_gt, total);
+    return hip_check(hipGetLastError(), "crop_augment_kernel");
+}
+
 // The same transpose for the case the generator needs (`feat`: NHWC bf16 -> NCHW f32, C % 8 == 0, HW % 4 == 0),
 // vectorised: 16-B loads of 8 channels, 16-B stores of 4 pixels; one element per thread and instruction left the
 // 56 MB copy at 2 TB/s.

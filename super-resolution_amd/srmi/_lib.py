@@ -67,6 +67,16 @@ class EpiDesc(C.Structure):
     ]
 
 
+class CropItem(C.Structure):
+    _fields_ = [
+        ("lr_offset", C.c_int64), ("gt_offset", C.c_int64),
+        ("lr_h", C.c_int32), ("lr_w", C.c_int32), ("iy", C.c_int32), ("ix", C.c_int32),
+        ("flags", C.c_int32), ("reserved", C.c_int32),
+    ]
+
+
+AUG_HFLIP, AUG_VFLIP, AUG_TRANSPOSE = 1, 2, 4
+
 # every symbol include/srmi.h declares: name -> (restype, argtypes)
 SYMBOLS = {
     "srmi_version": (C.c_int, []),
@@ -84,6 +94,8 @@ SYMBOLS = {
     "srmi_resblock_fwd": (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), C.c_void_p]),
     "srmi_layout_convert": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "srmi_crop_augment_u8": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                       C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "srmi_u8hwc_to_f32nchw": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "srmi_f32nchw_to_u8hwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_void_p]),

@@ -1,0 +1,51 @@
+"""Device data pipeline against batches the REFERENCE's `mydata` + `crop` + `augmentation` produced under a
+real torch DataLoader (tests/golden/dataset_pipeline.npz, oracle/make_golden_dataset.py): bit-exact, same seeds."""
+import importlib
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+D = importlib.import_module("super-resolution_amd.srmi.dataset")
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "dataset_pipeline.npz")
+
+
+def _dataset(z, in_memory):
+    n = int(z["n"])
+    imgs = ([z[f"lr{i}"] for i in range(n)], [z[f"gt{i}"] for i in range(n)])
+    tf = D.Compose([D.crop(int(z["scale"]), int(z["patch"])), D.augmentation()])
+    return D.mydata(in_memory=in_memory, transform=tf, images=imgs)
+
+
+@pytest.mark.parametrize("tag,in_memory,epochs", [("mem", True, 2), ("disk", False, 1)])
+def test_batches_match_reference_dataloader(tag, in_memory, epochs):
+    z = np.load(GOLD)
+    ds = _dataset(z, in_memory)
+    random.seed(int(z["seed"]))
+    torch.manual_seed(int(z["seed"]))
+    loader = ds.loader(batch_size=int(z["batch"]), shuffle=True)
+    k = 0
+    for _ in range(epochs):
+        for batch in loader:
+            assert batch["LR"].is_cuda and batch["LR"].dtype == torch.float32
+            assert np.array_equal(batch["LR"].cpu().numpy(), z[f"{tag}_LR{k}"]), f"LR batch {k}"
+            assert np.array_equal(batch["GT"].cpu().numpy(), z[f"{tag}_GT{k}"]), f"GT batch {k}"
+            k += 1
+    assert k == int(z[f"{tag}_batches"])
+
+
+def test_getitem_and_guards():
+    z = np.load(GOLD)
+    ds = _dataset(z, True)
+    random.seed(5)
+    item = ds[2]
+    assert item["LR"].shape == (3, 8, 8) and item["GT"].shape == (3, 32, 32) and item["LR"].dtype == np.float32
+    assert -1.0 <= item["LR"].min() and item["LR"].max() <= 1.0
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        D.mydata(in_memory=True, images=([], []), device="cpu")
+    plain = D.mydata(in_memory=True, images=([z["lr0"]], [z["gt0"]]))
+    with pytest.raises(NotImplementedError):
+        plain.batch([0])
