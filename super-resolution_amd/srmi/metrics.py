@@ -22,16 +22,17 @@ def ssim_window(h, w, scale):
     return win
 
 
-def y_psnr_ssim(gt: torch.Tensor, output: torch.Tensor, scale: int = 1, clip: bool = False, ssim: bool = True):
-    """(psnr, ssim) of image 0 of the batch as a 3-element float64 DEVICE tensor [mse, psnr, ssim].
+def y_psnr_ssim(gt: torch.Tensor, output: torch.Tensor, scale: int = 1, clip: bool = False, ssim: bool = True, index: int = 0):
+    """(psnr, ssim) of image `index` of the batch (the reference scores image 0, P/mode.py:31-32) as a 3-element
+    float64 DEVICE tensor [mse, psnr, ssim].
 
     gt may be larger than output; its top-left corner is used (P/mode.py:353)."""
     require_cuda(gt, "gt")
     require_cuda(output, "output")
     if output.dim() != 4 or gt.dim() != 4 or output.shape[1] != 3 or gt.shape[1] != 3:
         raise ValueError("y_psnr_ssim expects Nx3xHxW tensors")
-    o = output[0].float().contiguous()
-    g = gt[0].float().contiguous()
+    o = output[index].float().contiguous()
+    g = gt[index].float().contiguous()
     H, W = o.shape[1:]
     gH, gW = g.shape[1:]
     if scale < 1:
@@ -55,3 +56,31 @@ def calculate_metrics(gt, output, device=None, scale=1):
 def test_psnr(gt, output, scale):
     """PSNR of ``test`` (P/mode.py:353-373): output clipped to [-1,1], gt cropped to output's size."""
     return float(y_psnr_ssim(gt, output, scale=scale, clip=True, ssim=False)[1])
+
+
+def y_psnr_ssim_batch(gt: torch.Tensor, output: torch.Tensor, scale: int = 1, clip: bool = False, ssim: bool = True):
+    """[N, 3] float64 DEVICE tensor of [mse, psnr, ssim] for EVERY image of the batch: the reference scores
+    one image per call on the host; here N images are scored where they live, with no host synchronisation."""
+    n = min(gt.shape[0], output.shape[0])
+    return torch.stack([y_psnr_ssim(gt, output, scale=scale, clip=clip, ssim=ssim, index=i) for i in range(n)])
+
+
+class MetricAverager:
+    """Running mean of Y-PSNR / SSIM over a validation set, kept on the device: `update(gt, output)` per batch (any
+    image sizes from batch to batch), ONE 16-byte device->host copy in `result()`."""
+
+    def __init__(self, scale: int = 1, clip: bool = False):
+        self.scale, self.clip = scale, clip
+        self.sum = None
+        self.count = 0
+
+    def update(self, gt, output):
+        r = y_psnr_ssim_batch(gt, output, scale=self.scale, clip=self.clip)[:, 1:].sum(dim=0)
+        self.sum = r if self.sum is None else self.sum + r
+        self.count += min(gt.shape[0], output.shape[0])
+
+    def result(self):
+        if self.count == 0:
+            return float("nan"), float("nan")
+        m = (self.sum / self.count).cpu()
+        return float(m[0]), float(m[1])

@@ -100,3 +100,23 @@ def test_metric_properties_and_guards():
     out = torch.empty(3, dtype=torch.float64, device=DEV)
     rc = L.load().srmi_y_psnr_ssim(x.data_ptr(), x.data_ptr(), 64, 48, 64, 48, 4, 0, 4, out.data_ptr(), ws.data_ptr(), 0)
     assert rc == -1 and b"window" in L.load().srmi_last_error()
+
+
+def test_batched_metrics_and_averager():
+    """every image of a batch scored on the device; running mean over batches of different sizes."""
+    g = torch.Generator().manual_seed(31)
+    sets = [(3, 40, 56), (2, 64, 33)]
+    av = metrics.MetricAverager(scale=2)
+    ps, ss = [], []
+    for n, H, W in sets:
+        gt = torch.rand(n, 3, H, W, generator=g) * 2 - 1
+        out = gt + 0.05 * torch.randn(n, 3, H, W, generator=g)
+        r = metrics.y_psnr_ssim_batch(gt.to(DEV), out.to(DEV), scale=2)
+        assert r.shape == (n, 3) and r.is_cuda and r.dtype == torch.float64
+        for i in range(n):
+            p_ref, s_ref = M.calculate_metrics(gt[i:i + 1].numpy(), out[i:i + 1].numpy(), scale=2)
+            assert abs(float(r[i, 1]) - p_ref) <= 1e-4 and abs(float(r[i, 2]) - s_ref) <= 1e-6
+            ps.append(p_ref); ss.append(s_ref)
+        av.update(gt.to(DEV), out.to(DEV))
+    p, s = av.result()
+    assert abs(p - np.mean(ps)) <= 1e-4 and abs(s - np.mean(ss)) <= 1e-6
