@@ -59,3 +59,25 @@ def rrdbnet_forward(sd, x, num_blocks=16, num_dense_layers=3):
         x = depth_to_space_dcr(_conv(sd, f"up.{j}", x), 2)
         x = _prelu_c(x, sd[f"up_act.{j}.weight"])
     return torch.tanh(_conv(sd, "tail", x))
+
+
+def _bn_eval(sd, name, x, eps=1e-3):
+    """Keras BatchNormalization() at inference: (x - moving_mean) / sqrt(moving_var + 1e-3) * gamma + beta."""
+    return F.batch_norm(x, sd[name + ".running_mean"], sd[name + ".running_var"], sd[name + ".weight"], sd[name + ".bias"],
+                        training=False, eps=eps)
+
+
+def keras_srgan_forward(sd, x, num_res_blocks=16):
+    """`build_generator` of "Typical SRGAN with tensorflow/typical srgan .py":21-71: conv9x9 + PReLU(per channel) ·
+    N x [conv3x3, BN, PReLU, conv3x3, BN, + skip] · conv3x3, BN, + first · 2 x [conv3x3(64 -> 256), PReLU(256 slopes,
+    BEFORE the shuffle), depth_to_space(2)] · conv9x9(64 -> 3) tanh."""
+    x = _prelu_c(_conv(sd, "head", x), sd["head_act.weight"])
+    first = x
+    for b in range(num_res_blocks):
+        p = f"blocks.{b}"
+        t = _prelu_c(_bn_eval(sd, p + ".bn1", _conv(sd, p + ".conv1", x)), sd[p + ".act.weight"])
+        x = x + _bn_eval(sd, p + ".bn2", _conv(sd, p + ".conv2", t))
+    x = _bn_eval(sd, "post_bn", _conv(sd, "post", x)) + first
+    for j in range(2):
+        x = depth_to_space_dcr(_prelu_c(_conv(sd, f"up.{j}", x), sd[f"up_act.{j}.weight"]), 2)
+    return torch.tanh(_conv(sd, "tail", x))

@@ -1,4 +1,4 @@
-"""The reference's two Keras generators as torch modules on libsrmi's kernels:
+"""The reference's Keras generators as torch modules on libsrmi's kernels:
 
   * `SRCNN`   - SRCNN/srcnn.py:199-210: conv9x9(1->128)+ReLU, conv3x3(128->64)+ReLU, conv5x5(64->1); BASELINE config 2
                 ("9-1-5, 64/32") is `SRCNN(k=(9, 1, 5), ch=(64, 32))`.
@@ -6,6 +6,11 @@
                 N x [3 x (conv3x3 -> 32, LeakyReLU 0.2, concat) -> conv3x3(160 -> 64) x 0.2 + x] · conv3x3 + first ·
                 2 x [conv3x3(64 -> 256), depth_to_space(2), PReLU(per channel)] · conv3x3(64 -> 3) tanh.
                 The reference builds 16 blocks; BASELINE config 4 asks 23: `RRDBNet(num_blocks=23)`.
+
+  * `KerasSRGAN` - "Typical SRGAN with tensorflow/typical srgan .py":21-71: the SRResNet generator in its Keras layout:
+                per-channel PReLU everywhere, BatchNormalization eps 1e-3, PReLU on the 256 conv channels BEFORE
+                depth_to_space, and a 9x9 output conv (64 -> 3; no LDS-tiled kernel for that shape yet: it runs on
+                the generic f32-MFMA kernel).
 
 The Keras scripts are not importable (no TensorFlow here) and build their graph inline, so there is no module API
 to mirror; parameters are ordinary `nn.Conv2d` (OIHW) so torch tooling works, and `from_keras_hwio` converts a Keras
@@ -150,6 +155,64 @@ class RRDBNet(nn.Module, _ComputeMixin):
         self.up_act = nn.ModuleList([nn.PReLU(n_feats, init=0.0) for _ in range(2)])
         self.tail = _c(n_feats, img_ch, 3)
         self._plans = PlanCache(RRDBPlan)
+
+    def forward(self, x):
+        _guard(x, self)
+        N, _, H, W = x.shape
+        return self._plans.get(self, N, H, W, _COMPUTE[self.compute]).run(x)
+
+
+class _KResBlock(nn.Module):
+    def __init__(self, nf):
+        super().__init__()
+        self.conv1 = _c(nf, nf, 3)
+        self.bn1 = nn.BatchNorm2d(nf, eps=1e-3, momentum=0.01)       # Keras: epsilon 1e-3, momentum 0.99
+        self.act = nn.PReLU(nf, init=0.0)
+        self.conv2 = _c(nf, nf, 3)
+        self.bn2 = nn.BatchNorm2d(nf, eps=1e-3, momentum=0.01)
+
+
+class KerasSRGANPlan(_Plan):
+    def __init__(self, m, N, H, W, compute):
+        dev = next(m.parameters()).device
+        s = _Seq(dev, compute)
+        nf = m.n_feats
+        first = s.buf(N, H, W, nf)
+        s.add((m.head, None, m.head_act), None, first, N, H, W, in_layout=L.NCHW, in_dtype=L.F32)
+        cur, tmp, ping = first, s.buf(N, H, W, nf), [s.buf(N, H, W, nf), s.buf(N, H, W, nf)]
+        for i, blk in enumerate(m.blocks):
+            out = ping[i & 1]
+            s.add((blk.conv1, blk.bn1, blk.act), cur, tmp, N, H, W, fuse_next=True)     # one fused launch per block
+            s.add((blk.conv2, blk.bn2, None), tmp, out, N, H, W, residual=cur)
+            cur = out
+        t = s.buf(N, H, W, nf)
+        s.add((m.post, m.post_bn, None), cur, t, N, H, W, residual=first)
+        x, h, w = t, H, W
+        for j in range(2):
+            y = s.buf(N, 2 * h, 2 * w, nf)
+            s.add((m.up[j], None, m.up_act[j]), x, y, N, h, w, shuffle=2, shuffle_order=L.SHUFFLE_DCR)
+            x, h, w = y, 2 * h, 2 * w
+        self.out_shape = (N, m.tail.out_channels, h, w)
+        y0 = torch.empty(self.out_shape, dtype=torch.float32, device=dev)
+        s.add((m.tail, None, nn.Tanh()), x, y0, N, h, w, out_layout=L.NCHW, out_dtype=L.F32)
+        self.dev = dev
+        self.args, self.n = s.finish()
+        self.kernels, self._seq = s.kernels, s
+
+
+class KerasSRGAN(nn.Module, _ComputeMixin):
+    def __init__(self, num_res_blocks=16, n_feats=64, img_ch=3):
+        super().__init__()
+        self.n_feats = n_feats
+        self.head = _c(img_ch, n_feats, 9)
+        self.head_act = nn.PReLU(n_feats, init=0.0)
+        self.blocks = nn.ModuleList([_KResBlock(n_feats) for _ in range(num_res_blocks)])
+        self.post = _c(n_feats, n_feats, 3)
+        self.post_bn = nn.BatchNorm2d(n_feats, eps=1e-3, momentum=0.01)
+        self.up = nn.ModuleList([_c(n_feats, 4 * n_feats, 3) for _ in range(2)])
+        self.up_act = nn.ModuleList([nn.PReLU(4 * n_feats, init=0.0) for _ in range(2)])     # slopes of the conv channels
+        self.tail = _c(n_feats, img_ch, 9)
+        self._plans = PlanCache(KerasSRGANPlan)
 
     def forward(self, x):
         _guard(x, self)

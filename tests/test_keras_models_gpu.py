@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import keras_oracle as K
-from srmi.keras_models import SRCNN, RRDBNet, from_keras_hwio
+from srmi.keras_models import SRCNN, KerasSRGAN, RRDBNet, from_keras_hwio
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -79,3 +79,36 @@ def test_rrdbnet_bf16_psnr():
     p = _psnr01(y, ref)
     print("RRDB bf16 PSNR vs fp32 oracle: %.1f dB" % p)
     assert p >= 40.0
+
+
+def _randomise_bn(m, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, torch.nn.BatchNorm2d):
+                mod.weight.copy_(torch.empty(mod.weight.shape).uniform_(0.6, 1.4, generator=g))
+                mod.bias.copy_(torch.empty(mod.bias.shape).uniform_(-0.2, 0.2, generator=g))
+                mod.running_mean.copy_(torch.empty(mod.bias.shape).uniform_(-0.3, 0.3, generator=g))
+                mod.running_var.copy_(torch.empty(mod.bias.shape).uniform_(0.5, 1.5, generator=g))
+
+
+@pytest.mark.parametrize("nb,shape", [(2, (1, 3, 12, 16)), (3, (2, 3, 7, 100))])
+def test_keras_srgan_fp32_and_bf16(nb, shape):
+    """SURVEY 8f4 (first variant): the Keras-layout SRGAN generator (typical srgan .py:21-71).  Parity unpinned."""
+    m = KerasSRGAN(num_res_blocks=nb)
+    _randomise(m, 7)
+    _randomise_bn(m, 8)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.rand(shape, generator=torch.Generator().manual_seed(9)) * 2 - 1
+    with torch.no_grad():
+        ref = K.keras_srgan_forward(sd, x, num_res_blocks=nb)
+        m = m.to(DEV).eval()
+        y = m(x.to(DEV)).cpu()
+        assert y.shape == ref.shape == (shape[0], 3, 4 * shape[2], 4 * shape[3])
+        assert (y - ref).abs().max().item() / 2.0 <= 1e-4
+        yb = m.set_compute("bf16")(x.to(DEV)).cpu()
+        plan = m._plans.get(m, shape[0], shape[2], shape[3], 1)
+    assert plan.kernels[0] == "k9c3_bf16" and plan.kernels.count("c64_bf16") == 2 * nb + 3
+    p = _psnr01(yb, ref)
+    print("Keras SRGAN bf16 PSNR vs fp32 oracle: %.1f dB" % p)
+    assert p >= 35.0
