@@ -179,6 +179,18 @@ int srmi_u8hwc_to_f32nchw(const uint8_t* src, float* dst, int32_t N, int32_t H, 
 int srmi_f32nchw_to_u8hwc(const float* src, uint8_t* dst, int32_t N, int32_t H, int32_t W, int32_t C, int32_t clip,
                           void* stream);
 
+/* Inference-path addressing ops of the U-Net / autoencoder generator bodies (Keras MaxPooling2D((2,2)),
+ * UpSampling2D((2,2)) nearest, concatenate(axis=3): U-SRGAN/srganunet.py:44-77).  NHWC, dtype = SRMI_F32 | SRMI_BF16.
+ * Concatenation is never a copy: producers write channel slices of one buffer.
+ *   srmi_maxpool2x2_nhwc:   x has in_cstride channels per pixel (0 = C; x points at the slice's first channel), y is a
+ *                           dense [N, H/2, W/2, C] tensor; H, W are the INPUT size (floor, Keras padding='valid').
+ *   srmi_upsample2x_nhwc:   x dense [N, H, W, C]; y[n, 2h+i, 2w+j, out_coffset + c] = x[n, h, w, c] in a buffer with
+ *                           out_cstride channels per pixel (0 = C). */
+int srmi_maxpool2x2_nhwc(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_cstride,
+                         int32_t dtype, void* stream);
+int srmi_upsample2x_nhwc(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t out_cstride,
+                         int32_t out_coffset, int32_t dtype, void* stream);
+
 /* Training data pipeline on the device: `crop` + `augmentation` + normalisation + HWC->CHW of
  * `mydata.__getitem__` (P/dataset.py:27-49, :81-132) for a whole batch in one launch.  The dataset lives in device
  * memory as two packed uint8 HWC buffers (LR images, GT images; GT = scale x LR in both dimensions); `items` is a

@@ -81,3 +81,37 @@ def keras_srgan_forward(sd, x, num_res_blocks=16):
     for j in range(2):
         x = depth_to_space_dcr(_prelu_c(_conv(sd, f"up.{j}", x), sd[f"up_act.{j}.weight"]), 2)
     return torch.tanh(_conv(sd, "tail", x))
+
+
+def _conv_block(sd, p, x):
+    """`conv_block` (U-SRGAN/srganunet.py:14-30): (conv3x3, BN, ReLU) x 2 (dropout 0)."""
+    x = F.relu(_bn_eval(sd, p + ".bn1", _conv(sd, p + ".conv1", x)))
+    return F.relu(_bn_eval(sd, p + ".bn2", _conv(sd, p + ".conv2", x)))
+
+
+def unet_forward(sd, x, depth=4):
+    """`UNet` (U-SRGAN/srganunet.py:32-86): `depth` x (conv_block, MaxPooling2D(2)), bottleneck conv_block,
+    `depth` x (UpSampling2D(2) nearest, concatenate([up, skip]), conv_block), conv1x1 -> 64."""
+    skips = []
+    for d in range(depth):
+        x = _conv_block(sd, f"unet.down.{d}", x)
+        skips.append(x)
+        x = F.max_pool2d(x, 2)
+    x = _conv_block(sd, "unet.mid", x)
+    for d in range(depth):
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+        x = torch.cat([x, skips[depth - 1 - d]], dim=1)
+        x = _conv_block(sd, f"unet.up.{d}", x)
+    return _conv(sd, "unet.final", x)
+
+
+def unet_srgan_forward(sd, x, depth=4):
+    """`build_unet_srgan_generator` (U-SRGAN/srganunet.py:90-126): conv9x9 + PReLU · UNet · conv3x3, BN,
+    Concatenate([., skip]) · 2 x [conv3x3(-> 1024), PReLU, depth_to_space(2)] · conv9x9(256 -> 3) tanh."""
+    x = _prelu_c(_conv(sd, "head", x), sd["head_act.weight"])
+    skip = x
+    x = unet_forward(sd, x, depth)
+    x = torch.cat([_bn_eval(sd, "post_bn", _conv(sd, "post", x)), skip], dim=1)
+    for j in range(2):
+        x = depth_to_space_dcr(_prelu_c(_conv(sd, f"up.{j}", x), sd[f"up_act.{j}.weight"]), 2)
+    return torch.tanh(_conv(sd, "tail", x))

@@ -67,6 +67,7 @@ int wgrad_launch(const srmi_conv_desc& d, const ConvGeom& g, const float* x, con
 
 int u8_to_f32(const unsigned char* src, float* dst, int N, int H, int W, int C, hipStream_t s);
 int f32_to_u8(const float* src, unsigned char* dst, int N, int H, int W, int C, int clip, hipStream_t s);
+int pool_up_launch(int op, const void* x, void* y, int N, int H, int W, int C, int cs, int co, int dtype, hipStream_t s);
 int crop_augment(const unsigned char* lr_pack, const unsigned char* gt_pack, const srmi_crop_item* items, int B, int patch,
                  int scale, int C, int f32_arith, float* lr_out, float* gt_out, hipStream_t s);
 
@@ -294,6 +295,29 @@ int srmi_conv2d_fwd_seq(const srmi_conv_args* a, int32_t n, void* stream) {
 
 // investigation only, not declared in srmi.h: phase time stamps of the last traced chain launch (SRMI_DBG bit 16384)
 int srmi_debug_chain_trace(unsigned long long* out, int n) { return resblock_chain_trace(out, n); }
+
+int srmi_maxpool2x2_nhwc(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_cstride,
+                         int32_t dtype, void* stream) {
+    if (N < 0 || H < 0 || W < 0 || C <= 0 || in_cstride < 0 || (in_cstride && in_cstride < C) || !is_dtype(dtype)) {
+        set_error("maxpool2x2_nhwc: bad arguments");
+        return SRMI_EINVAL;
+    }
+    if ((size_t)N * (H / 2) * (W / 2) == 0) return SRMI_OK;
+    if (!x || !y) { set_error("maxpool2x2_nhwc: NULL buffer"); return SRMI_EINVAL; }
+    return pool_up_launch(0, x, y, N, H, W, C, in_cstride ? in_cstride : C, 0, dtype, (hipStream_t)stream);
+}
+
+int srmi_upsample2x_nhwc(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t out_cstride,
+                         int32_t out_coffset, int32_t dtype, void* stream) {
+    const int cs = out_cstride ? out_cstride : C;
+    if (N < 0 || H < 0 || W < 0 || C <= 0 || out_cstride < 0 || out_coffset < 0 || out_coffset + C > cs || !is_dtype(dtype)) {
+        set_error("upsample2x_nhwc: bad arguments");
+        return SRMI_EINVAL;
+    }
+    if ((size_t)N * H * W == 0) return SRMI_OK;
+    if (!x || !y) { set_error("upsample2x_nhwc: NULL buffer"); return SRMI_EINVAL; }
+    return pool_up_launch(1, x, y, N, H, W, C, cs, out_coffset, dtype, (hipStream_t)stream);
+}
 
 int srmi_crop_augment_u8(const uint8_t* lr_pack, const uint8_t* gt_pack, const srmi_crop_item* items, int32_t B,
                          int32_t patch, int32_t scale, int32_t C, int32_t f32_arith, float* lr_out, float* gt_out,

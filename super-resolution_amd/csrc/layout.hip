@@ -106,6 +106,60 @@ int f32_to_u8(const float* src, unsigned char* dst, int N, int H, int W, int C, 
     return hip_check(hipGetLastError(), "f32nchw_to_u8hwc_kernel");
 }
 
+// ---- addressing ops of the U-Net / autoencoder generator bodies (inference, NHWC, f32 or bf16) -------------------
+template <typename T>
+__device__ __forceinline__ float pool_val(T v);
+template <> __device__ __forceinline__ float pool_val<float>(float v) { return v; }
+template <> __device__ __forceinline__ float pool_val<bf16_t>(bf16_t v) { return bf2f(v); }
+
+template <typename T>
+__global__ void maxpool2x2_nhwc_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int W, int C, int in_cs, size_t total) {
+    const int Ho = H / 2, Wo = W / 2;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        size_t t = idx / C;
+        const int ox = (int)(t % Wo); t /= Wo;
+        const int oy = (int)(t % Ho);
+        const size_t n = t / Ho;
+        const T* b = x + ((n * H + 2 * oy) * W + 2 * ox) * in_cs + c;
+        const T v00 = b[0], v01 = b[in_cs], v10 = b[(size_t)W * in_cs], v11 = b[(size_t)W * in_cs + in_cs];
+        T m = v00;                       // the stored value itself is returned (no re-rounding), first maximum wins
+        if (pool_val(v01) > pool_val(m)) m = v01;
+        if (pool_val(v10) > pool_val(m)) m = v10;
+        if (pool_val(v11) > pool_val(m)) m = v11;
+        y[idx] = m;
+    }
+}
+
+template <typename T>
+__global__ void upsample2x_nhwc_kernel(const T* __restrict__ x, T* __restrict__ y, int H, int W, int C, int out_cs, int out_co,
+                                       size_t total) {
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(idx % C);
+        size_t t = idx / C;
+        const int ox = (int)(t % (2 * W)); t /= 2 * W;
+        const int oy = (int)(t % (2 * H));
+        const size_t n = t / (2 * H);
+        y[((n * 2 * H + oy) * 2 * W + ox) * out_cs + out_co + c] = x[((n * H + oy / 2) * W + ox / 2) * C + c];
+    }
+}
+
+int pool_up_launch(int op, const void* x, void* y, int N, int H, int W, int C, int cs, int co, int dtype, hipStream_t s) {
+    const size_t total = op == 0 ? (size_t)N * (H / 2) * (W / 2) * C : (size_t)N * 4 * H * W * C;
+    if (total == 0) return SRMI_OK;
+    size_t blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    const dim3 g((unsigned)blocks), b(256);
+    if (op == 0) {
+        if (dtype == SRMI_F32) hipLaunchKernelGGL(maxpool2x2_nhwc_kernel<float>, g, b, 0, s, (const float*)x, (float*)y, H, W, C, cs, total);
+        else hipLaunchKernelGGL(maxpool2x2_nhwc_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)x, (bf16_t*)y, H, W, C, cs, total);
+    } else {
+        if (dtype == SRMI_F32) hipLaunchKernelGGL(upsample2x_nhwc_kernel<float>, g, b, 0, s, (const float*)x, (float*)y, H, W, C, cs, co, total);
+        else hipLaunchKernelGGL(upsample2x_nhwc_kernel<bf16_t>, g, b, 0, s, (const bf16_t*)x, (bf16_t*)y, H, W, C, cs, co, total);
+    }
+    return hip_check(hipGetLastError(), op == 0 ? "maxpool2x2_nhwc_kernel" : "upsample2x_nhwc_kernel");
+}
+
 // crop + augmentation + normalisation + HWC->CHW of one training batch (P/dataset.py:27-49, :81-132).
 // Output element (b, c, oy, ox) of the final patch = T(V(H(patch))): undo the transpose, then the vertical, then the
 // horizontal flip to find the source pixel.  One launch covers the LR and the GT outputs (GT elements first).

@@ -12,6 +12,11 @@
                 depth_to_space, and a 9x9 output conv (64 -> 3; no LDS-tiled kernel for that shape yet: it runs on
                 the generic f32-MFMA kernel).
 
+  * `UNetSRGAN` - U-SRGAN/srganunet.py:14-126: 9x9 head, a 4-level U-Net body (conv blocks 64..1024, MaxPooling2D,
+                nearest UpSampling2D, channel concatenation), concat with the head output, two 1024-channel sub-pixel
+                convs and a 9x9 output conv.  Concatenations are never copies (channel-slice stores); pooling and
+                upsampling are the two addressing kernels `srmi_maxpool2x2_nhwc` / `srmi_upsample2x_nhwc`.
+
 The Keras scripts are not importable (no TensorFlow here) and build their graph inline, so there is no module API
 to mirror; parameters are ordinary `nn.Conv2d` (OIHW) so torch tooling works, and `from_keras_hwio` converts a Keras
 kernel.  Tensors are NCHW like the rest of this package (Keras is NHWC).  The channel concat of the dense block is
@@ -213,6 +218,142 @@ class KerasSRGAN(nn.Module, _ComputeMixin):
         self.up_act = nn.ModuleList([nn.PReLU(4 * n_feats, init=0.0) for _ in range(2)])     # slopes of the conv channels
         self.tail = _c(n_feats, img_ch, 9)
         self._plans = PlanCache(KerasSRGANPlan)
+
+    def forward(self, x):
+        _guard(x, self)
+        N, _, H, W = x.shape
+        return self._plans.get(self, N, H, W, _COMPUTE[self.compute]).run(x)
+
+
+class _ConvBlock(nn.Module):
+    """`conv_block` (U-SRGAN/srganunet.py:14-30)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.conv1 = _c(cin, cout, 3)
+        self.bn1 = nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01)
+        self.conv2 = _c(cout, cout, 3)
+        self.bn2 = nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01)
+
+
+class _UNet(nn.Module):
+    def __init__(self, nf=64, depth=4):
+        super().__init__()
+        w = [nf * (1 << d) for d in range(depth + 1)]                       # 64, 128, 256, 512, 1024
+        self.down = nn.ModuleList([_ConvBlock(nf if d == 0 else w[d - 1], w[d]) for d in range(depth)])
+        self.mid = _ConvBlock(w[depth - 1], w[depth])
+        self.up = nn.ModuleList([_ConvBlock(w[depth - d] + w[depth - 1 - d], w[depth - 1 - d]) for d in range(depth)])
+        self.final = _c(nf, nf, 1)
+
+
+class UNetSRGANPlan:
+    """Conv runs go out through `srmi_conv2d_fwd_seq`; between them the pooling / upsampling launches.  Every
+    concatenation is a buffer whose producers write channel slices: level L of the U-Net owns
+    cat_L = [ upsampled decoder input (2*cw) | encoder skip (cw) ] and the tail owns [ post conv (nf) | head output (nf) ]."""
+
+    def __init__(self, m, N, H, W, compute):
+        dev = next(m.parameters()).device
+        depth = len(m.unet.down)
+        if H % (1 << depth) or W % (1 << depth):
+            raise ValueError(f"UNetSRGAN: input {H}x{W} must be divisible by {1 << depth} (Keras' concatenate needs equal sizes)")
+        s = _Seq(dev, compute)
+        relu = nn.ReLU()
+        nf = m.n_feats
+        self.steps = []          # ("conv", first layer index, count) | ("pool", src, dst, N, h, w, C, in_cs) | ("up", ...)
+        mark = [0]
+
+        def flush():
+            n = len(s.layers) - mark[0]
+            if n:
+                self.steps.append(("conv", mark[0], n))
+            mark[0] = len(s.layers)
+
+        tailcat = s.buf(N, H, W, 2 * nf)
+        s.add((m.head, None, m.head_act), None, tailcat, N, H, W, in_layout=L.NCHW, in_dtype=L.F32, out_cstride=2 * nf,
+              out_coffset=nf)
+        x, xcs, h, w = tailcat[..., nf:], 2 * nf, H, W           # a channel-slice view: data_ptr() is the slice start
+        cats = []
+        for blk in m.unet.down:
+            cw = blk.conv1.out_channels
+            cat = s.buf(N, h, w, 3 * cw)
+            t = s.buf(N, h, w, cw)
+            s.add((blk.conv1, blk.bn1, relu), x, t, N, h, w, in_cstride=xcs)
+            s.add((blk.conv2, blk.bn2, relu), t, cat, N, h, w, out_cstride=3 * cw, out_coffset=2 * cw)
+            flush()
+            pooled = s.buf(N, h // 2, w // 2, cw)
+            self.steps.append(("pool", cat[..., 2 * cw:], pooled, N, h, w, cw, 3 * cw))
+            cats.append((cat, cw, h, w))
+            x, xcs, h, w = pooled, 0, h // 2, w // 2
+        t = s.buf(N, h, w, m.unet.mid.conv1.out_channels)
+        y = s.buf(N, h, w, m.unet.mid.conv2.out_channels)
+        s.add((m.unet.mid.conv1, m.unet.mid.bn1, relu), x, t, N, h, w)
+        s.add((m.unet.mid.conv2, m.unet.mid.bn2, relu), t, y, N, h, w)
+        flush()
+        x = y
+        for d, blk in enumerate(m.unet.up):
+            cat, cw, ch, cwid = cats[depth - 1 - d]
+            assert x.shape[-1] == 2 * cw and (ch, cwid) == (2 * h, 2 * w)
+            flush()                                              # the convs that produce x run before it is upsampled
+            self.steps.append(("up", x, cat, N, h, w, 2 * cw, 3 * cw, 0))
+            h, w = ch, cwid
+            t = s.buf(N, h, w, blk.conv1.out_channels)
+            y = s.buf(N, h, w, blk.conv2.out_channels)
+            s.add((blk.conv1, blk.bn1, relu), cat, t, N, h, w)
+            s.add((blk.conv2, blk.bn2, relu), t, y, N, h, w)
+            x = y
+        u = s.buf(N, h, w, nf)
+        s.add((m.unet.final, None, None), x, u, N, h, w)
+        s.add((m.post, m.post_bn, None), u, tailcat, N, h, w, out_cstride=2 * nf, out_coffset=0)
+        x = tailcat
+        for j in range(2):
+            co = m.up[j].out_channels
+            y = s.buf(N, 2 * h, 2 * w, co // 4)
+            s.add((m.up[j], None, m.up_act[j]), x, y, N, h, w, shuffle=2, shuffle_order=L.SHUFFLE_DCR)
+            x, h, w = y, 2 * h, 2 * w
+        self.out_shape = (N, m.tail.out_channels, h, w)
+        y0 = torch.empty(self.out_shape, dtype=torch.float32, device=dev)
+        s.add((m.tail, None, nn.Tanh()), x, y0, N, h, w, out_layout=L.NCHW, out_dtype=L.F32)
+        flush()
+        self.dev, self.adt = dev, s.adt
+        self.args, self.n = s.finish()
+        self.kernels, self._seq = s.kernels, s
+
+    def run(self, x):
+        import ctypes as C
+        lib = L.load()
+        x = x.contiguous().float()
+        self._x = x
+        y = torch.empty(self.out_shape, dtype=torch.float32, device=self.dev)
+        self.args[0].x = x.data_ptr()
+        self.args[self.n - 1].y = y.data_ptr()
+        st = Fn.stream_ptr()
+        for step in self.steps:
+            if step[0] == "conv":
+                _, i0, n = step
+                sub = C.cast(C.byref(self.args, i0 * C.sizeof(L.ConvArgs)), C.POINTER(L.ConvArgs))
+                L.check(lib.srmi_conv2d_fwd_seq(sub, n, st))
+            elif step[0] == "pool":
+                _, src, dst, N, h, w, c, cs = step
+                L.check(lib.srmi_maxpool2x2_nhwc(src.data_ptr(), dst.data_ptr(), N, h, w, c, cs, self.adt, st))
+            else:
+                _, src, dst, N, h, w, c, cs, co = step
+                L.check(lib.srmi_upsample2x_nhwc(src.data_ptr(), dst.data_ptr(), N, h, w, c, cs, co, self.adt, st))
+        return y
+
+
+class UNetSRGAN(nn.Module, _ComputeMixin):
+    def __init__(self, n_feats=64, depth=4, img_ch=3, up_feats=256):
+        super().__init__()
+        self.n_feats = n_feats
+        self.head = _c(img_ch, n_feats, 9)
+        self.head_act = nn.PReLU(n_feats, init=0.0)
+        self.unet = _UNet(n_feats, depth)
+        self.post = _c(n_feats, n_feats, 3)
+        self.post_bn = nn.BatchNorm2d(n_feats, eps=1e-3, momentum=0.01)
+        self.up = nn.ModuleList([_c(2 * n_feats, 4 * up_feats, 3), _c(up_feats, 4 * up_feats, 3)])
+        self.up_act = nn.ModuleList([nn.PReLU(4 * up_feats, init=0.0) for _ in range(2)])
+        self.tail = _c(up_feats, img_ch, 9)
+        self._plans = PlanCache(UNetSRGANPlan)
 
     def forward(self, x):
         _guard(x, self)

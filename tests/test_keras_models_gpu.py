@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import keras_oracle as K
-from srmi.keras_models import SRCNN, KerasSRGAN, RRDBNet, from_keras_hwio
+from srmi.keras_models import SRCNN, KerasSRGAN, RRDBNet, UNetSRGAN, from_keras_hwio
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -112,3 +112,26 @@ def test_keras_srgan_fp32_and_bf16(nb, shape):
     p = _psnr01(yb, ref)
     print("Keras SRGAN bf16 PSNR vs fp32 oracle: %.1f dB" % p)
     assert p >= 35.0
+
+
+@pytest.mark.parametrize("kw,shape", [(dict(n_feats=64, depth=2, up_feats=64), (1, 3, 8, 12)), (dict(n_feats=64, depth=4), (1, 3, 16, 32))])
+def test_unet_srgan_fp32_and_bf16(kw, shape):
+    """the U-Net generator (U-SRGAN/srganunet.py:14-126) - pooling, nearest upsampling and concatenation as
+    addressing.  Parity unpinned (no TensorFlow): compared with oracle/keras_oracle.py."""
+    m = UNetSRGAN(**kw)
+    _randomise(m, 11)
+    _randomise_bn(m, 12)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.rand(shape, generator=torch.Generator().manual_seed(13)) * 2 - 1
+    with torch.no_grad():
+        ref = K.unet_srgan_forward(sd, x, depth=kw["depth"])
+        m = m.to(DEV).eval()
+        y = m(x.to(DEV)).cpu()
+        assert y.shape == ref.shape == (shape[0], 3, 4 * shape[2], 4 * shape[3])
+        assert (y - ref).abs().max().item() / 2.0 <= 1e-4
+        yb = m.set_compute("bf16")(x.to(DEV)).cpu()
+    p = _psnr01(yb, ref)
+    print("U-Net SRGAN bf16 PSNR vs fp32 oracle: %.1f dB" % p)
+    assert p >= 35.0
+    with pytest.raises(ValueError, match="divisible"):
+        m(torch.zeros(1, 3, 10, 12, device=DEV))

@@ -329,3 +329,25 @@ def test_fused_resblock_kernel(case):
     # aliasing the input is refused before any launch
     Fn.fill_args(a2, d2, tmp, wp[1], scd[1], shd[1], None, xd, xd)
     assert L.load().srmi_resblock_fwd(C.byref(a1), C.byref(a2), Fn.stream_ptr()) == -2
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pool_and_upsample_addressing_ops(dtype):
+    """srmi_maxpool2x2_nhwc (channel-slice input, floor sizes) and srmi_upsample2x_nhwc (store into a channel slice)."""
+    lib = L.load()
+    code = L.F32 if dtype == torch.float32 else L.BF16
+    g = torch.Generator().manual_seed(17)
+    N, H, W, Cc, CS, off = 2, 7, 9, 24, 40, 8
+    buf = torch.randn(N, H, W, CS, generator=g).to(dtype).to(DEV)
+    y = torch.empty(N, H // 2, W // 2, Cc, dtype=dtype, device=DEV)
+    L.check(lib.srmi_maxpool2x2_nhwc(buf[..., off:].data_ptr(), y.data_ptr(), N, H, W, Cc, CS, code, Fn.stream_ptr()))
+    ref = torch.nn.functional.max_pool2d(buf[..., off:off + Cc].float().permute(0, 3, 1, 2), 2).permute(0, 2, 3, 1)
+    assert torch.equal(y.float(), ref)
+    x = torch.randn(N, 3, 5, Cc, generator=g).to(dtype).to(DEV)
+    out = torch.full((N, 6, 10, CS), 7.0, dtype=dtype, device=DEV)
+    L.check(lib.srmi_upsample2x_nhwc(x.data_ptr(), out.data_ptr(), N, 3, 5, Cc, CS, off, code, Fn.stream_ptr()))
+    up = x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+    assert torch.equal(out[..., off:off + Cc], up)
+    assert torch.all(out[..., :off] == 7.0) and torch.all(out[..., off + Cc:] == 7.0)
+    assert lib.srmi_upsample2x_nhwc(x.data_ptr(), out.data_ptr(), N, 3, 5, Cc, CS, CS - 4, code, None) == -1     # slice overruns
+    assert lib.srmi_maxpool2x2_nhwc(None, None, 0, 4, 4, 8, 0, code, None) == 0                                   # empty batch
