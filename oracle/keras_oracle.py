@@ -115,3 +115,26 @@ def unet_srgan_forward(sd, x, depth=4):
     for j in range(2):
         x = depth_to_space_dcr(_prelu_c(_conv(sd, f"up.{j}", x), sd[f"up_act.{j}.weight"]), 2)
     return torch.tanh(_conv(sd, "tail", x))
+
+
+def autoencoder_block(sd, p, x):
+    """`autoencoder_block` (A-SRGAN/srganautoencoders.py:55-104): two conv+PReLU, pool, two conv+PReLU, pool, bottleneck
+    conv+PReLU, upsample, two conv+PReLU (+ e5), upsample, two conv+PReLU (+ e2)."""
+    c = lambda name, t: _prelu_c(_conv(sd, f"{p}.{name}", t), sd[f"{p}.{name}_act.weight"])
+    e2 = c("e2", c("e1", x))
+    e5 = c("e5", c("e4", F.max_pool2d(e2, 2)))
+    b = c("b", F.max_pool2d(e5, 2))
+    d3 = c("d3", c("d2", F.interpolate(b, scale_factor=2, mode="nearest"))) + e5
+    return c("d6", c("d5", F.interpolate(d3, scale_factor=2, mode="nearest"))) + e2
+
+
+def autoencoder_srgan_forward(sd, x, num_autoencoders=1):
+    """`build_autoencoder_srgan_generator` (A-SRGAN/srganautoencoders.py:106-144)."""
+    x = _prelu_c(_conv(sd, "head", x), sd["head_act.weight"])
+    skip = x
+    for i in range(num_autoencoders):
+        x = autoencoder_block(sd, f"blocks.{i}", x)
+    x = _bn_eval(sd, "post_bn", _conv(sd, "post", x)) + skip
+    for j in range(2):
+        x = depth_to_space_dcr(_prelu_c(_conv(sd, f"up.{j}", x), sd[f"up_act.{j}.weight"]), 2)
+    return torch.tanh(_conv(sd, "tail", x))

@@ -17,6 +17,9 @@
                 convs and a 9x9 output conv.  Concatenations are never copies (channel-slice stores); pooling and
                 upsampling are the two addressing kernels `srmi_maxpool2x2_nhwc` / `srmi_upsample2x_nhwc`.
 
+  * `AutoencoderSRGAN` - A-SRGAN/srganautoencoders.py:55-144: stacked encoder/decoder blocks (conv + per-channel PReLU,
+                MaxPooling2D, UpSampling2D, additive skips fused into the conv epilogues) between the SRGAN head and tail.
+
 The Keras scripts are not importable (no TensorFlow here) and build their graph inline, so there is no module API
 to mirror; parameters are ordinary `nn.Conv2d` (OIHW) so torch tooling works, and `from_keras_hwio` converts a Keras
 kernel.  Tensors are NCHW like the rest of this package (Keras is NHWC).  The channel concat of the dense block is
@@ -354,6 +357,98 @@ class UNetSRGAN(nn.Module, _ComputeMixin):
         self.up_act = nn.ModuleList([nn.PReLU(4 * up_feats, init=0.0) for _ in range(2)])
         self.tail = _c(up_feats, img_ch, 9)
         self._plans = PlanCache(UNetSRGANPlan)
+
+    def forward(self, x):
+        _guard(x, self)
+        N, _, H, W = x.shape
+        return self._plans.get(self, N, H, W, _COMPUTE[self.compute]).run(x)
+
+
+class _AEBlock(nn.Module):
+    _LAYERS = (("e1", 0, 0), ("e2", 0, 0), ("e4", 0, 1), ("e5", 1, 1), ("b", 1, 2), ("d2", 2, 1), ("d3", 1, 1), ("d5", 1, 0), ("d6", 0, 0))
+
+    def __init__(self, nf_in, f):
+        super().__init__()
+        for name, i, o in self._LAYERS:
+            cin = nf_in if name == "e1" else f[i]
+            setattr(self, name, _c(cin, f[o], 3))
+            setattr(self, name + "_act", nn.PReLU(f[o], init=0.0))
+
+
+class AutoencoderSRGANPlan(UNetSRGANPlan):
+    def __init__(self, m, N, H, W, compute):
+        dev = next(m.parameters()).device
+        if H % 4 or W % 4:
+            raise ValueError(f"AutoencoderSRGAN: input {H}x{W} must be divisible by 4 (the additive skips need equal sizes)")
+        s = _Seq(dev, compute)
+        f = m.num_filters
+        self.steps = []
+        mark = [0]
+
+        def flush():
+            n = len(s.layers) - mark[0]
+            if n:
+                self.steps.append(("conv", mark[0], n))
+            mark[0] = len(s.layers)
+
+        def conv(blk, name, x, h, w, residual=None):
+            c2d = getattr(blk, name)
+            y = s.buf(N, h, w, c2d.out_channels)
+            s.add((c2d, None, getattr(blk, name + "_act")), x, y, N, h, w, residual=residual)
+            return y
+
+        def pool(x, h, w):
+            flush()
+            y = s.buf(N, h // 2, w // 2, x.shape[-1])
+            self.steps.append(("pool", x, y, N, h, w, x.shape[-1], 0))
+            return y
+
+        def up(x, h, w):
+            flush()
+            y = s.buf(N, 2 * h, 2 * w, x.shape[-1])
+            self.steps.append(("up", x, y, N, h, w, x.shape[-1], 0, 0))
+            return y
+
+        first = s.buf(N, H, W, f[0])
+        s.add((m.head, None, m.head_act), None, first, N, H, W, in_layout=L.NCHW, in_dtype=L.F32)
+        x = first
+        for blk in m.blocks:
+            e2 = conv(blk, "e2", conv(blk, "e1", x, H, W), H, W)
+            e5 = conv(blk, "e5", conv(blk, "e4", pool(e2, H, W), H // 2, W // 2), H // 2, W // 2)
+            b = conv(blk, "b", pool(e5, H // 2, W // 2), H // 4, W // 4)
+            d3 = conv(blk, "d3", conv(blk, "d2", up(b, H // 4, W // 4), H // 2, W // 2), H // 2, W // 2, residual=e5)
+            x = conv(blk, "d6", conv(blk, "d5", up(d3, H // 2, W // 2), H, W), H, W, residual=e2)
+        t = s.buf(N, H, W, m.post.out_channels)
+        s.add((m.post, m.post_bn, None), x, t, N, H, W, residual=first)
+        x, h, w = t, H, W
+        for j in range(2):
+            co = m.up[j].out_channels
+            y = s.buf(N, 2 * h, 2 * w, co // 4)
+            s.add((m.up[j], None, m.up_act[j]), x, y, N, h, w, shuffle=2, shuffle_order=L.SHUFFLE_DCR)
+            x, h, w = y, 2 * h, 2 * w
+        self.out_shape = (N, m.tail.out_channels, h, w)
+        y0 = torch.empty(self.out_shape, dtype=torch.float32, device=dev)
+        s.add((m.tail, None, nn.Tanh()), x, y0, N, h, w, out_layout=L.NCHW, out_dtype=L.F32)
+        flush()
+        self.dev, self.adt = dev, s.adt
+        self.args, self.n = s.finish()
+        self.kernels, self._seq = s.kernels, s
+
+
+class AutoencoderSRGAN(nn.Module, _ComputeMixin):
+    def __init__(self, num_autoencoders=1, num_filters=(64, 128, 256), img_ch=3):
+        super().__init__()
+        f = tuple(num_filters)
+        self.num_filters = f
+        self.head = _c(img_ch, f[0], 9)
+        self.head_act = nn.PReLU(f[0], init=0.0)
+        self.blocks = nn.ModuleList([_AEBlock(f[0], f) for _ in range(num_autoencoders)])
+        self.post = _c(f[0], 64, 3)
+        self.post_bn = nn.BatchNorm2d(64, eps=1e-3, momentum=0.01)
+        self.up = nn.ModuleList([_c(64, 4 * f[2], 3), _c(f[2], 4 * f[2], 3)])
+        self.up_act = nn.ModuleList([nn.PReLU(4 * f[2], init=0.0) for _ in range(2)])
+        self.tail = _c(f[2], img_ch, 9)
+        self._plans = PlanCache(AutoencoderSRGANPlan)
 
     def forward(self, x):
         _guard(x, self)

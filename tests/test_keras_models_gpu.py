@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import keras_oracle as K
-from srmi.keras_models import SRCNN, KerasSRGAN, RRDBNet, UNetSRGAN, from_keras_hwio
+from srmi.keras_models import SRCNN, AutoencoderSRGAN, KerasSRGAN, RRDBNet, UNetSRGAN, from_keras_hwio
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -135,3 +135,23 @@ def test_unet_srgan_fp32_and_bf16(kw, shape):
     assert p >= 35.0
     with pytest.raises(ValueError, match="divisible"):
         m(torch.zeros(1, 3, 10, 12, device=DEV))
+
+
+@pytest.mark.parametrize("kw,shape", [(dict(num_autoencoders=1), (1, 3, 8, 12)), (dict(num_autoencoders=3, num_filters=(64, 128, 256)), (2, 3, 12, 16))])
+def test_autoencoder_srgan_fp32_and_bf16(kw, shape):
+    """the stacked-autoencoder generator (A-SRGAN/srganautoencoders.py:55-144).  Parity unpinned."""
+    m = AutoencoderSRGAN(**kw)
+    _randomise(m, 21)
+    _randomise_bn(m, 22)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.rand(shape, generator=torch.Generator().manual_seed(23)) * 2 - 1
+    with torch.no_grad():
+        ref = K.autoencoder_srgan_forward(sd, x, num_autoencoders=kw["num_autoencoders"])
+        m = m.to(DEV).eval()
+        y = m(x.to(DEV)).cpu()
+        assert y.shape == ref.shape == (shape[0], 3, 4 * shape[2], 4 * shape[3])
+        assert (y - ref).abs().max().item() / 2.0 <= 1e-4
+        yb = m.set_compute("bf16")(x.to(DEV)).cpu()
+    p = _psnr01(yb, ref)
+    print("Autoencoder SRGAN bf16 PSNR vs fp32 oracle: %.1f dB" % p)
+    assert p >= 35.0
