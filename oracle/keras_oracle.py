@@ -138,3 +138,31 @@ def autoencoder_srgan_forward(sd, x, num_autoencoders=1):
     for j in range(2):
         x = depth_to_space_dcr(_prelu_c(_conv(sd, f"up.{j}", x), sd[f"up_act.{j}.weight"]), 2)
     return torch.tanh(_conv(sd, "tail", x))
+
+
+def _res_conv_block(sd, p, x):
+    """`res_conv_block` (Res-U-SRGAN/untitled0.py:39-73): conv3x3, BN, ReLU, conv3x3, BN; shortcut conv1x1, BN;
+    ReLU(shortcut + conv)."""
+    c = F.relu(_bn_eval(sd, p + ".bn1", _conv(sd, p + ".conv1", x)))
+    c = _bn_eval(sd, p + ".bn2", _conv(sd, p + ".conv2", c))
+    return F.relu(_bn_eval(sd, p + ".bn_s", _conv(sd, p + ".shortcut", x)) + c)
+
+
+def res_unet_srgan_forward(sd, x, depth=4):
+    """`build_unet_srgan_generator` of Res-U-SRGAN/untitled0.py:190-226 around `Res_UNet` (:76-125).  The generator's
+    post conv + BN is dead in the reference graph (its output is overwritten by Add([skip, u_net_output]), :207-209), so
+    the model is head -> Res_UNet -> + head output -> two sub-pixel stages -> conv9x9 tanh."""
+    x = _prelu_c(_conv(sd, "head", x), sd["head_act.weight"])
+    skip, skips = x, []
+    for d in range(depth):
+        x = _res_conv_block(sd, f"unet.down.{d}", x)
+        skips.append(x)
+        x = F.max_pool2d(x, 2)
+    x = _res_conv_block(sd, "unet.mid", x)
+    for d in range(depth):
+        x = torch.cat([F.interpolate(x, scale_factor=2, mode="nearest"), skips[depth - 1 - d]], dim=1)
+        x = _res_conv_block(sd, f"unet.up.{d}", x)
+    x = _conv(sd, "unet.final", x) + skip
+    for j in range(2):
+        x = depth_to_space_dcr(_prelu_c(_conv(sd, f"up.{j}", x), sd[f"up_act.{j}.weight"]), 2)
+    return torch.tanh(_conv(sd, "tail", x))

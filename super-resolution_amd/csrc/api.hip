@@ -90,7 +90,7 @@ int conv_geom(const srmi_conv_desc& d, ConvGeom* g) {
         set_error("conv desc: bad compute code %d", d.compute);
         return SRMI_EINVAL;
     }
-    if (d.act < SRMI_ACT_NONE || d.act > SRMI_ACT_SIGMOID) {
+    if (d.act < SRMI_ACT_NONE || d.act > SRMI_ACT_ADD_RELU) {
         set_error("conv desc: bad activation code %d", d.act);
         return SRMI_EINVAL;
     }

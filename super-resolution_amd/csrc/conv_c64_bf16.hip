@@ -306,7 +306,7 @@ bool c64_supported(const srmi_conv_desc& d) {
     if (d.in_dtype != SRMI_BF16 || d.out_dtype != SRMI_BF16) return false;
     if (d.in_layout != SRMI_NHWC || d.out_layout != SRMI_NHWC) return false;
     if (d.shuffle != 1 && !(d.shuffle == 2 && d.Cout == 256)) return false;
-    if (d.act == SRMI_ACT_TANH || d.act == SRMI_ACT_SIGMOID) return false;
+    if (d.act == SRMI_ACT_TANH || d.act == SRMI_ACT_SIGMOID || d.act == SRMI_ACT_ADD_RELU) return false;
     const int in_cs = d.in_cstride ? d.in_cstride : d.Cin;
     if (in_cs % 8 != 0) return false;
     // the staging addresses one image through a 32-bit buffer descriptor with two out-of-range markers

@@ -290,7 +290,7 @@ bool cin_supported(const srmi_conv_desc& d) {
     if (d.Cin % 32 != 0 || d.Cin < 32 || d.Cin > 1024 || d.Cout % 32 != 0 || d.Cout > 1024) return false;
     if (d.in_dtype != SRMI_BF16 || d.out_dtype != SRMI_BF16) return false;
     if (d.in_layout != SRMI_NHWC || d.out_layout != SRMI_NHWC) return false;
-    if (d.act == SRMI_ACT_TANH || d.act == SRMI_ACT_SIGMOID) return false;
+    if (d.act == SRMI_ACT_TANH || d.act == SRMI_ACT_SIGMOID || d.act == SRMI_ACT_ADD_RELU) return false;
     const int in_cs = d.in_cstride ? d.in_cstride : d.Cin;
     const int out_cs = d.out_cstride ? d.out_cstride : d.Cout;
     const int res_cs = d.res_cstride ? d.res_cstride : d.Cout;

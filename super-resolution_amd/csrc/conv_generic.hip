@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(GenericParams p) {
             const int n_r = __shfl(n, row), oy_r = __shfl(oy, row), ox_r = __shfl(ox, row);
             if (!cvalid || m0 + row >= p.M) continue;
             const int Y = oy_r * p.r + si, X = ox_r * p.r + sj;
-            float val = apply_act(acc[t][e] * sc + sh, p.act, p.act_param, al);
+            const bool late = p.act == SRMI_ACT_ADD_RELU;   // the residual joins before the ReLU
+            float val = late ? acc[t][e] * sc + sh : apply_act(acc[t][e] * sc + sh, p.act, p.act_param, al);
             size_t oidx, ridx;
             if (p.out_nchw) {
                 oidx = (((size_t)n_r * p.Cf + c) * p.Hf + Y) * p.Wf + X;
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(GenericParams p) {
                 continue;
             }
             if (p.res) val += p.res_bf16 ? bf2f(((const bf16_t*)p.res)[ridx]) : ((const float*)p.res)[ridx];
+            if (late) val = fmaxf(val, 0.f);
             if (p.out_bf16) ((bf16_t*)p.y)[oidx] = f2bf(val);
             else ((float*)p.y)[oidx] = val;
         }

@@ -183,7 +183,7 @@ bool k9c3_supported(const srmi_conv_desc& d) {
     if (d.kh != 9 || d.kw != 9 || d.stride != 1 || d.pad != 4) return false;
     if (d.Cin < 1 || d.Cin > 3 || d.Cout % 64 != 0 || d.Cout > 512 || d.shuffle != 1) return false;
     if (d.out_dtype != SRMI_BF16 || d.out_layout != SRMI_NHWC) return false;
-    if (d.act == SRMI_ACT_TANH || d.act == SRMI_ACT_SIGMOID) return false;
+    if (d.act == SRMI_ACT_TANH || d.act == SRMI_ACT_SIGMOID || d.act == SRMI_ACT_ADD_RELU) return false;
     const int out_cs = d.out_cstride ? d.out_cstride : d.Cout;
     if (out_cs % 8 != 0 || d.out_coffset % 8 != 0) return false;
     return true;

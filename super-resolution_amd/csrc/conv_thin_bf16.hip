@@ -252,7 +252,7 @@ __global__ void thin_pack_kernel(const float* __restrict__ w, bf16_t* __restrict
 }
 
 bool thin_supported(const srmi_conv_desc& d) {
-    if (d.compute != SRMI_COMPUTE_BF16) return false;
+    if (d.compute != SRMI_COMPUTE_BF16 || d.act == SRMI_ACT_ADD_RELU) return false;
     if (d.kh != 3 || d.kw != 3 || d.stride != 1 || d.pad != 1 || d.Cin != 64) return false;
     if (d.Cout < 1 || d.Cout > 4 || d.shuffle != 1) return false;
     if (d.in_dtype != SRMI_BF16 || d.in_layout != SRMI_NHWC) return false;

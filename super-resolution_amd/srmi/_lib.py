@@ -15,7 +15,7 @@ import os
 F32, BF16 = 0, 1
 NHWC, NCHW = 0, 1
 COMPUTE_F32, COMPUTE_BF16 = 0, 1
-ACT_NONE, ACT_PRELU, ACT_LRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID = 0, 1, 2, 3, 4, 5
+ACT_NONE, ACT_PRELU, ACT_LRELU, ACT_RELU, ACT_TANH, ACT_SIGMOID, ACT_ADD_RELU = 0, 1, 2, 3, 4, 5, 6
 SHUFFLE_CRD, SHUFFLE_DCR = 0, 1
 
 

@@ -37,6 +37,11 @@ def require_cuda(t: torch.Tensor, what="input"):
             "(there is deliberately no CPU fallback)")
 
 
+class AddReLU(nn.Module):
+    """Marker for the one epilogue whose activation follows the residual: relu(conv + residual), the
+    `add([shortcut, conv])` -> ReLU of res_conv_block (Res-U-SRGAN/untitled0.py:67-72).  Only meaningful inside a plan."""
+
+
 def act_of(module):
     """Map the activation module the reference passes around (P/srgan_model.py:8,43; P/ops.py:28-29)
     to (act code, param, alpha tensor or None, per_channel)."""
@@ -52,6 +57,8 @@ def act_of(module):
         return L.ACT_TANH, 0.0, None, 0
     if isinstance(module, nn.Sigmoid):
         return L.ACT_SIGMOID, 0.0, None, 0
+    if isinstance(module, AddReLU):
+        return L.ACT_ADD_RELU, 0.0, None, 0
     raise NotImplementedError(f"srmi: activation {type(module).__name__} has no fused epilogue")
 
 

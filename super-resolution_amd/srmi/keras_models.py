@@ -20,6 +20,9 @@
   * `AutoencoderSRGAN` - A-SRGAN/srganautoencoders.py:55-144: stacked encoder/decoder blocks (conv + per-channel PReLU,
                 MaxPooling2D, UpSampling2D, additive skips fused into the conv epilogues) between the SRGAN head and tail.
 
+  * `ResUNetSRGAN` - Res-U-SRGAN/untitled0.py:39-125, 190-226: the U-Net with residual conv blocks (conv-BN-ReLU-conv-BN plus
+                a 1x1 conv-BN shortcut, ReLU after the add = the SRMI_ACT_ADD_RELU epilogue).
+
 The Keras scripts are not importable (no TensorFlow here) and build their graph inline, so there is no module API
 to mirror; parameters are ordinary `nn.Conv2d` (OIHW) so torch tooling works, and `from_keras_hwio` converts a Keras
 kernel.  Tensors are NCHW like the rest of this package (Keras is NHWC).  The channel concat of the dense block is
@@ -449,6 +452,112 @@ class AutoencoderSRGAN(nn.Module, _ComputeMixin):
         self.up_act = nn.ModuleList([nn.PReLU(4 * f[2], init=0.0) for _ in range(2)])
         self.tail = _c(f[2], img_ch, 9)
         self._plans = PlanCache(AutoencoderSRGANPlan)
+
+    def forward(self, x):
+        _guard(x, self)
+        N, _, H, W = x.shape
+        return self._plans.get(self, N, H, W, _COMPUTE[self.compute]).run(x)
+
+
+class _ResConvBlock(nn.Module):
+    """`res_conv_block` (Res-U-SRGAN/untitled0.py:39-73)."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        bn = lambda: nn.BatchNorm2d(cout, eps=1e-3, momentum=0.01)
+        self.conv1, self.bn1 = _c(cin, cout, 3), bn()
+        self.conv2, self.bn2 = _c(cout, cout, 3), bn()
+        self.shortcut, self.bn_s = _c(cin, cout, 1), bn()
+
+
+class _ResUNet(nn.Module):
+    def __init__(self, nf=64, depth=4):
+        super().__init__()
+        w = [nf * (1 << d) for d in range(depth + 1)]
+        self.down = nn.ModuleList([_ResConvBlock(nf if d == 0 else w[d - 1], w[d]) for d in range(depth)])
+        self.mid = _ResConvBlock(w[depth - 1], w[depth])
+        self.up = nn.ModuleList([_ResConvBlock(w[depth - d] + w[depth - 1 - d], w[depth - 1 - d]) for d in range(depth)])
+        self.final = _c(nf, nf, 1)
+
+
+class ResUNetSRGANPlan(UNetSRGANPlan):
+    def __init__(self, m, N, H, W, compute):
+        dev = next(m.parameters()).device
+        depth = len(m.unet.down)
+        if H % (1 << depth) or W % (1 << depth):
+            raise ValueError(f"ResUNetSRGAN: input {H}x{W} must be divisible by {1 << depth} (Keras' concatenate needs equal sizes)")
+        s = _Seq(dev, compute)
+        relu, add_relu = nn.ReLU(), Fn.AddReLU()
+        nf = m.n_feats
+        self.steps = []
+        mark = [0]
+
+        def flush():
+            n = len(s.layers) - mark[0]
+            if n:
+                self.steps.append(("conv", mark[0], n))
+            mark[0] = len(s.layers)
+
+        def block(blk, x, h, w, y, in_cs=0, **out):
+            cw = blk.conv1.out_channels
+            sc, t = s.buf(N, h, w, cw), s.buf(N, h, w, cw)
+            s.add((blk.shortcut, blk.bn_s, None), x, sc, N, h, w, in_cstride=in_cs)
+            s.add((blk.conv1, blk.bn1, relu), x, t, N, h, w, in_cstride=in_cs)
+            s.add((blk.conv2, blk.bn2, add_relu), t, y, N, h, w, residual=sc, **out)
+
+        first = s.buf(N, H, W, nf)
+        s.add((m.head, None, m.head_act), None, first, N, H, W, in_layout=L.NCHW, in_dtype=L.F32)
+        x, h, w = first, H, W
+        cats = []
+        for blk in m.unet.down:
+            cw = blk.conv1.out_channels
+            cat = s.buf(N, h, w, 3 * cw)
+            block(blk, x, h, w, cat, out_cstride=3 * cw, out_coffset=2 * cw)
+            flush()
+            pooled = s.buf(N, h // 2, w // 2, cw)
+            self.steps.append(("pool", cat[..., 2 * cw:], pooled, N, h, w, cw, 3 * cw))
+            cats.append((cat, cw, h, w))
+            x, h, w = pooled, h // 2, w // 2
+        y = s.buf(N, h, w, m.unet.mid.conv2.out_channels)
+        block(m.unet.mid, x, h, w, y)
+        x = y
+        for d, blk in enumerate(m.unet.up):
+            cat, cw, ch, cwid = cats[depth - 1 - d]
+            assert x.shape[-1] == 2 * cw and (ch, cwid) == (2 * h, 2 * w)
+            flush()
+            self.steps.append(("up", x, cat, N, h, w, 2 * cw, 3 * cw, 0))
+            h, w = ch, cwid
+            y = s.buf(N, h, w, blk.conv2.out_channels)
+            block(blk, cat, h, w, y)
+            x = y
+        u = s.buf(N, h, w, nf)
+        s.add((m.unet.final, None, None), x, u, N, h, w, residual=first)
+        x = u
+        for j in range(2):
+            co = m.up[j].out_channels
+            y = s.buf(N, 2 * h, 2 * w, co // 4)
+            s.add((m.up[j], None, m.up_act[j]), x, y, N, h, w, shuffle=2, shuffle_order=L.SHUFFLE_DCR)
+            x, h, w = y, 2 * h, 2 * w
+        self.out_shape = (N, m.tail.out_channels, h, w)
+        y0 = torch.empty(self.out_shape, dtype=torch.float32, device=dev)
+        s.add((m.tail, None, nn.Tanh()), x, y0, N, h, w, out_layout=L.NCHW, out_dtype=L.F32)
+        flush()
+        self.dev, self.adt = dev, s.adt
+        self.args, self.n = s.finish()
+        self.kernels, self._seq = s.kernels, s
+
+
+class ResUNetSRGAN(nn.Module, _ComputeMixin):
+    def __init__(self, n_feats=64, depth=4, img_ch=3, up_feats=256):
+        super().__init__()
+        self.n_feats = n_feats
+        self.head = _c(img_ch, n_feats, 9)
+        self.head_act = nn.PReLU(n_feats, init=0.0)
+        self.unet = _ResUNet(n_feats, depth)
+        self.up = nn.ModuleList([_c(n_feats, 4 * up_feats, 3), _c(up_feats, 4 * up_feats, 3)])
+        self.up_act = nn.ModuleList([nn.PReLU(4 * up_feats, init=0.0) for _ in range(2)])
+        self.tail = _c(up_feats, img_ch, 9)
+        self._plans = PlanCache(ResUNetSRGANPlan)
 
     def forward(self, x):
         _guard(x, self)

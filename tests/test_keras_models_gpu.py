@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from oracle import keras_oracle as K
-from srmi.keras_models import SRCNN, AutoencoderSRGAN, KerasSRGAN, RRDBNet, UNetSRGAN, from_keras_hwio
+from srmi.keras_models import SRCNN, AutoencoderSRGAN, KerasSRGAN, ResUNetSRGAN, RRDBNet, UNetSRGAN, from_keras_hwio
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -154,4 +154,25 @@ def test_autoencoder_srgan_fp32_and_bf16(kw, shape):
         yb = m.set_compute("bf16")(x.to(DEV)).cpu()
     p = _psnr01(yb, ref)
     print("Autoencoder SRGAN bf16 PSNR vs fp32 oracle: %.1f dB" % p)
+    assert p >= 35.0
+
+
+@pytest.mark.parametrize("kw,shape", [(dict(n_feats=64, depth=2, up_feats=64), (2, 3, 8, 12)), (dict(n_feats=64, depth=4), (1, 3, 16, 32))])
+def test_res_unet_srgan_fp32_and_bf16(kw, shape):
+    """the residual U-Net generator (Res-U-SRGAN/untitled0.py:39-125, 190-226); its ReLU-after-add blocks use
+    the SRMI_ACT_ADD_RELU epilogue.  Parity unpinned (no TensorFlow): compared with oracle/keras_oracle.py."""
+    m = ResUNetSRGAN(**kw)
+    _randomise(m, 31)
+    _randomise_bn(m, 32)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.rand(shape, generator=torch.Generator().manual_seed(33)) * 2 - 1
+    with torch.no_grad():
+        ref = K.res_unet_srgan_forward(sd, x, depth=kw["depth"])
+        m = m.to(DEV).eval()
+        y = m(x.to(DEV)).cpu()
+        assert y.shape == ref.shape == (shape[0], 3, 4 * shape[2], 4 * shape[3])
+        assert (y - ref).abs().max().item() / 2.0 <= 1e-4
+        yb = m.set_compute("bf16")(x.to(DEV)).cpu()
+    p = _psnr01(yb, ref)
+    print("Res-U-Net SRGAN bf16 PSNR vs fp32 oracle: %.1f dB" % p)
     assert p >= 35.0

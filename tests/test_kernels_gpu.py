@@ -41,6 +41,8 @@ def _ref_fused(x_nchw, w, scale, shift, act, act_param, alpha, residual_nchw, st
             z = F.pixel_shuffle(z, r)
     if residual_nchw is not None:
         z = z + residual_nchw.double()
+    if act == L.ACT_ADD_RELU:   # the one activation that follows the residual
+        z = F.relu(z)
     return z
 
 
@@ -148,6 +150,9 @@ def test_layout_convert_exact():
     dict(N=1, H=12, W=12, Cin=64, Cout=1, k=5),                                                 # SRCNN layer 3
     dict(N=1, H=8, W=8, Cin=96, Cout=32, k=3, act=L.ACT_LRELU, act_param=0.2, in_cs=160, out_cs=160, out_co=96),  # RRDB dense
     dict(N=1, H=5, W=40, Cin=20, Cout=40, k=3, act=L.ACT_RELU),                                 # ragged channels
+    dict(N=2, H=11, W=13, Cin=64, Cout=64, k=3, act=L.ACT_ADD_RELU, residual=True),             # res_conv_block: relu(conv + shortcut)
+    dict(N=1, H=6, W=8, Cin=128, Cout=64, k=3, act=L.ACT_ADD_RELU, residual=True, out_cs=192, out_co=128),
+    dict(N=1, H=6, W=8, Cin=64, Cout=64, k=3, act=L.ACT_ADD_RELU),                              # no residual: a plain ReLU
 ])
 def test_generic_f32_kernel(case):
     assert _run_case(**case) == "generic_f32"
@@ -157,6 +162,8 @@ def test_generic_f32_kernel(case):
     dict(N=2, H=11, W=13, Cin=64, Cout=64, k=3, act=L.ACT_PRELU),
     dict(N=1, H=6, W=5, Cin=64, Cout=256, k=3, act=L.ACT_PRELU, r=2),
     dict(N=2, H=10, W=12, Cin=64, Cout=3, k=3, act=L.ACT_TANH, out_layout=L.NCHW),
+    dict(N=2, H=11, W=13, Cin=64, Cout=64, k=3, act=L.ACT_ADD_RELU, residual=True),
+    dict(N=2, H=11, W=13, Cin=64, Cout=64, k=3, act=L.ACT_ADD_RELU, residual=True, compute=L.COMPUTE_BF16),  # no LDS-tiled kernel takes it
 ])
 def test_generic_kernel_bf16_storage(case):
     assert _run_case(io=torch.bfloat16, **case) == "generic_f32"
