@@ -52,8 +52,9 @@ extern "C" {
 #define SRMI_ACT_TANH 4    /* nn.Tanh, P/srgan_model.py:25 */
 #define SRMI_ACT_SIGMOID 5 /* nn.Sigmoid, P/srgan_model.py:60 */
 #define SRMI_ACT_ADD_RELU 6 /* the one activation applied AFTER the residual: y = relu(conv*scale + shift + residual), the
-                               `add([shortcut, conv])` -> ReLU of res_conv_block (Res-U-SRGAN/untitled0.py:67-72).  Generic
-                               kernel only (both compute modes select it); residual == NULL makes it a plain ReLU */
+                               `add([shortcut, conv])` -> ReLU of res_conv_block (Res-U-SRGAN/untitled0.py:67-72).  Served by the
+                               generic kernel and, for bf16 3x3 convs, the K-chunked bf16 kernel; residual == NULL makes
+                               it a plain ReLU */
 /* sub-pixel store orders (shuffle > 1) */
 #define SRMI_SHUFFLE_CRD 0 /* nn.PixelShuffle: conv channel = c*r*r + i*r + j   (P/ops.py:75) */
 #define SRMI_SHUFFLE_DCR 1 /* tf.nn.depth_to_space: conv channel = (i*r + j)*C + c (ESRGAN/untitled0.py:60) */

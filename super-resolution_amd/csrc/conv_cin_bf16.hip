@@ -215,6 +215,8 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_cin_kernel(CinParams p) {
     }
 
     // ---- epilogue: scale/shift -> slope activation -> + residual (channel-slice strides) -> bf16 store ----
+    // SRMI_ACT_ADD_RELU: the slope stage is the identity (slope 1) and the ReLU follows the residual add.
+    const bool late_relu = p.act == SRMI_ACT_ADD_RELU;
     // channel map (cin_row_to_cl): lane (pl, q) holds, of channel tile t, rows 4q..4q+3; with NCT = 4 these are
     // channels 8q..8q+7 and 32+8q..32+8q+7 of the group (two 16-B stores), with NCT = 2 channels 8q..8q+7 (one).
     constexpr int NH = NCT / 2;                        // 8-channel runs per lane
@@ -249,6 +251,10 @@ __global__ __launch_bounds__(NW * 64, 1) void conv_cin_kernel(CinParams p) {
                     v[2 * e] += bf2f((bf16_t)(r[e] & 0xffffu));
                     v[2 * e + 1] += bf2f((bf16_t)(r[e] >> 16));
                 }
+            }
+            if (late_relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
             }
             u32x4 o;
 #pragma unroll
@@ -290,7 +296,7 @@ bool cin_supported(const srmi_conv_desc& d) {
     if (d.Cin % 32 != 0 || d.Cin < 32 || d.Cin > 1024 || d.Cout % 32 != 0 || d.Cout > 1024) return false;
     if (d.in_dtype != SRMI_BF16 || d.out_dtype != SRMI_BF16) return false;
     if (d.in_layout != SRMI_NHWC || d.out_layout != SRMI_NHWC) return false;
-    if (d.act == SRMI_ACT_TANH || d.act == SRMI_ACT_SIGMOID || d.act == SRMI_ACT_ADD_RELU) return false;
+    if (d.act == SRMI_ACT_TANH || d.act == SRMI_ACT_SIGMOID) return false;
     const int in_cs = d.in_cstride ? d.in_cstride : d.Cin;
     const int out_cs = d.out_cstride ? d.out_cstride : d.Cout;
     const int res_cs = d.res_cstride ? d.res_cstride : d.Cout;

@@ -163,7 +163,7 @@ def test_generic_f32_kernel(case):
     dict(N=1, H=6, W=5, Cin=64, Cout=256, k=3, act=L.ACT_PRELU, r=2),
     dict(N=2, H=10, W=12, Cin=64, Cout=3, k=3, act=L.ACT_TANH, out_layout=L.NCHW),
     dict(N=2, H=11, W=13, Cin=64, Cout=64, k=3, act=L.ACT_ADD_RELU, residual=True),
-    dict(N=2, H=11, W=13, Cin=64, Cout=64, k=3, act=L.ACT_ADD_RELU, residual=True, compute=L.COMPUTE_BF16),  # no LDS-tiled kernel takes it
+    dict(N=2, H=11, W=13, Cin=64, Cout=64, k=1, act=L.ACT_ADD_RELU, residual=True, compute=L.COMPUTE_BF16),  # 1x1: no LDS-tiled kernel
 ])
 def test_generic_kernel_bf16_storage(case):
     assert _run_case(io=torch.bfloat16, **case) == "generic_f32"
@@ -206,6 +206,10 @@ def test_c64_bf16_kernel(case):
     dict(N=2, H=6, W=96, Cin=512, Cout=64, act=L.ACT_RELU),                   # VGG-width contraction
     dict(N=1, H=15, W=120, Cin=160, Cout=64, residual=True, res_cs=160),      # 8 x 64 tile, ragged
     dict(N=1, H=16, W=128, Cin=96, Cout=32, act=L.ACT_LRELU, act_param=0.2, in_cs=160, out_cs=160, out_co=96),
+    # res_conv_block's relu(conv + shortcut) (Res-U-SRGAN/untitled0.py:67-72): the activation after the residual
+    dict(N=2, H=11, W=13, Cin=64, Cout=64, act=L.ACT_ADD_RELU, residual=True),
+    dict(N=1, H=13, W=100, Cin=192, Cout=128, act=L.ACT_ADD_RELU, residual=True, out_cs=384, out_co=256),
+    dict(N=1, H=6, W=10, Cin=128, Cout=128, act=L.ACT_ADD_RELU),
 ])
 def test_cin_bf16_kernel(case):
     name = _run_case(k=3, io=torch.bfloat16, compute=L.COMPUTE_BF16, **case)
