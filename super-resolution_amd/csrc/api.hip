@@ -20,6 +20,7 @@ void set_error(const char* fmt, ...) {
 //               Cin=64 kernel: staging / MFMA loop / epilogue)
 //   32          disable the XCD-aware block -> tile remap        128  4-wave fused ResBlock
 //   256         4-wave Cin=64 / K-chunked kernels                512  fused ResBlock without the residual read
+//   bits 23-24  thin-Cout kernel: cache policy of its row loads (0 = nt, the default; 1 = none; 2 = nt+sc1...), bit 25: nt stores
 int dbg_flags() {
     static const int v = [] { const char* e = getenv("SRMI_DBG"); return e ? atoi(e) : 0; }();
     return v;

@@ -61,7 +61,22 @@ __device__ __forceinline__ float thin_act(float v, int act, float param, float a
     }
 }
 
-template <bool TANH>   // TANH: the activation is known at compile time (no switch in the per-row epilogue)
+#define THIN_DMA3(MOD)                                                                                         \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" MOD "\n\t"       \
+                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off" MOD "\n\t"                   \
+                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %3, off" MOD "\n\ts_mov_b32 m0, %0"   \
+                 : "=&s"(keep) : "v"(s0), "v"(s1), "v"(s2), "s"(dst) : "memory", "scc")
+#define THIN_DMA2(MOD)                                                                                         \
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" MOD "\n\t"       \
+                 "s_add_u32 m0, m0, 0x1000\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off" MOD "\n\ts_mov_b32 m0, %0"   \
+                 : "=&s"(keep) : "v"(s0), "v"(s1), "s"(dst) : "memory", "scc")
+
+// TANH: the activation is known at compile time (no switch in the per-row epilogue).  CH: cache policy of the
+// streaming row loads (low two bits: 0 default, 1 nt, 2 sc1, 3 sc0 sc1) and of the output stores (bit 2: nt).
+// The launcher uses nt loads: the 302 MB input is read once, and keeping it out of the caches is worth 8 us here
+// and 7 us to the up conv that runs before it in the next forward; SRMI_DBG bits 23-25 select
+// the other policies for measurement.
+template <bool TANH, int CH = 0>
 __global__ __launch_bounds__(256, 2) void conv_thin_kernel(ThinParams p) {
     __shared__ __attribute__((aligned(16))) unsigned char lds[THIN_NS * THIN_SLOT_BYTES];
 
@@ -106,34 +121,15 @@ __global__ __launch_bounds__(256, 2) void conv_thin_kernel(ThinParams p) {
         unsigned keep;
         if (wave == 0) {
             const unsigned char* s2 = (rowok && coloff[2] >= 0) ? rowp + coloff[2] : zero_blk + (lane & 3) * 16;
-            asm volatile(
-                "s_mov_b32 %0, m0\n\t"
-                "s_mov_b32 m0, %4\n\t"
-                "s_nop 0\n\t"
-                "global_load_lds_dwordx4 %1, off\n\t"
-                "s_add_u32 m0, m0, 0x1000\n\t"
-                "s_nop 0\n\t"
-                "global_load_lds_dwordx4 %2, off\n\t"
-                "s_add_u32 m0, m0, 0x1000\n\t"
-                "s_nop 0\n\t"
-                "global_load_lds_dwordx4 %3, off\n\t"
-                "s_mov_b32 m0, %0"
-                : "=&s"(keep)
-                : "v"(s0), "v"(s1), "v"(s2), "s"(dst)
-                : "memory", "scc");
+            if constexpr ((CH & 3) == 1) THIN_DMA3(" nt");
+            else if constexpr (CH == 2) THIN_DMA3(" sc1");
+            else if constexpr (CH == 3) THIN_DMA3(" sc0 sc1");
+            else THIN_DMA3("");
         } else {
-            asm volatile(
-                "s_mov_b32 %0, m0\n\t"
-                "s_mov_b32 m0, %3\n\t"
-                "s_nop 0\n\t"
-                "global_load_lds_dwordx4 %1, off\n\t"
-                "s_add_u32 m0, m0, 0x1000\n\t"
-                "s_nop 0\n\t"
-                "global_load_lds_dwordx4 %2, off\n\t"
-                "s_mov_b32 m0, %0"
-                : "=&s"(keep)
-                : "v"(s0), "v"(s1), "s"(dst)
-                : "memory", "scc");
+            if constexpr ((CH & 3) == 1) THIN_DMA2(" nt");
+            else if constexpr (CH == 2) THIN_DMA2(" sc1");
+            else if constexpr (CH == 3) THIN_DMA2(" sc0 sc1");
+            else THIN_DMA2("");
         }
     };
 #pragma unroll
@@ -214,8 +210,9 @@ __global__ __launch_bounds__(256, 2) void conv_thin_kernel(ThinParams p) {
             const float z = a[e] * sc[e] + sh[e];
             const float val = (p.dbg & 4) ? z : (TANH ? thin_tanh(z) : thin_act(z, p.act, p.act_param, al[e]));
             const unsigned off = (ok && e < p.Cout) ? off0 + (unsigned)e * cstep : 0xfffffff0u;   // out of range: dropped
-            if (p.out_bf16) __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(val), yres, off, 0, 0);
-            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), yres, off, 0, 0);
+            constexpr int AUX = (CH & 4) ? 2 : 0;      // 2 = nt
+            if (p.out_bf16) __builtin_amdgcn_raw_buffer_store_b16((short)f2bf(val), yres, off, 0, AUX);
+            else __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, val), yres, off, 0, AUX);
         }
         if (p.Cout == 4) {                 // rare 4-channel case: drain first so the static vmcnt arithmetic holds
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -302,7 +299,14 @@ int thin_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     p.bands = (d.H + rb - 1) / rb;
     const long long nb = (long long)d.N * p.strips * p.bands;
     if (nb > 0x7fffffffLL) { set_error("c64_thin_bf16: grid too large"); return SRMI_EINVAL; }
-    if (d.act == SRMI_ACT_TANH) hipLaunchKernelGGL(conv_thin_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, p);
+    int ch = ((p.dbg >> 23) & 3) ^ 1;     // cache policy of the streaming loads: nt unless SRMI_DBG bits 23-24 say otherwise
+    if (ch == 1 && (p.dbg & (1 << 25))) ch = 5;     // experiment: nt output stores too
+    if (d.act == SRMI_ACT_TANH && ch == 5) hipLaunchKernelGGL((conv_thin_kernel<true, 5>), dim3((unsigned)nb), dim3(256), 0, s, p); else
+    if (d.act == SRMI_ACT_TANH && ch == 1) hipLaunchKernelGGL((conv_thin_kernel<true, 1>), dim3((unsigned)nb), dim3(256), 0, s, p);
+    else if (d.act == SRMI_ACT_TANH && ch == 2) hipLaunchKernelGGL((conv_thin_kernel<true, 2>), dim3((unsigned)nb), dim3(256), 0, s, p);
+    else if (d.act == SRMI_ACT_TANH && ch == 3) hipLaunchKernelGGL((conv_thin_kernel<true, 3>), dim3((unsigned)nb), dim3(256), 0, s, p);
+    else if (d.act == SRMI_ACT_TANH) hipLaunchKernelGGL(conv_thin_kernel<true>, dim3((unsigned)nb), dim3(256), 0, s, p);
+    else if (ch & 1) hipLaunchKernelGGL((conv_thin_kernel<false, 1>), dim3((unsigned)nb), dim3(256), 0, s, p);
     else hipLaunchKernelGGL(conv_thin_kernel<false>, dim3((unsigned)nb), dim3(256), 0, s, p);
     return hip_check(hipGetLastError(), "conv_thin_kernel");
 }
