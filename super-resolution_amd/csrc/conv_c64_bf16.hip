@@ -365,9 +365,10 @@ int c64_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     p.stagger = 0; p.first_round = 256;
     { const char* e = getenv("SRMI_STAGGER"); if (e) p.stagger = atoi(e); }
     // Two workgroups per CU (6 x 48 tiles) once the launch has several rounds of them: they drift out of phase and
-    // hide each other's staging, epilogue and store waits.  (One round runs in lockstep and gains nothing.)
+    // hide each other's staging, epilogue and store waits.  (One round runs in lockstep: it gains nothing with several
+    // channel chunks - 64->256 at 96x96: 47.5 -> 48.8 us - and 1 us with one - 64->64 at 96x96: 22.5 -> 21.5 us.)
     const long long nb2 = (long long)d.N * ((d.W + 47) / 48) * ((d.H + 5) / 6);
-    const bool two = tile == 0 && p.nchunk <= 4 && !w4 && ((p.dbg & (1 << 21)) ? false : ((p.dbg & (1 << 22)) ? true : nb2 >= 1024));
+    const bool two = tile == 0 && p.nchunk <= 4 && !w4 && ((p.dbg & (1 << 21)) ? false : ((p.dbg & (1 << 22)) ? true : nb2 >= (p.nchunk == 1 ? 512 : 1024)));
     if (two) {
         p.first_round = 512;
         p.tiles_x = (d.W + 47) / 48; p.tiles_y = (d.H + 5) / 6;

@@ -7,5 +7,5 @@ for d in ${THIN_ABLATE:-0 2 4 8 10 14}; do
   SRMI_DBG=$d timeout -k 10 120 python3 bench.py --no-cpu-baseline --steps 30 --warmup 5 | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print({k.split('@')[0]:v['ms'] for k,v in d['roofline']['layers'].items()}, d['ms_per_step'])"
+print({k.split(':')[1].replace('x96k3','').replace('x192k3','').replace('x384k3',''):v['ms'] for k,v in d['roofline']['layers'].items()}, d['ms_per_step'])"
 done
