@@ -95,3 +95,29 @@ def test_null_arguments_rejected_without_launch():
     assert lib.srmi_conv2d_fwd(C.byref(a), None) == 0            # empty batch: nothing to launch
     assert lib.srmi_layout_convert(None, None, 0, 3, 8, 8, 1, 0, 0, 1, None) == 0
     assert lib.srmi_layout_convert(None, None, 1, 3, 8, 8, 1, 0, 0, 1, None) == -1
+
+
+def test_python_constants_match_header():
+    """Every SRMI_* integer #define of include/srmi.h that srmi/_lib.py mirrors (name minus the prefix) has the same value."""
+    import os
+    import re
+    hdr = open(os.path.join(os.path.dirname(__file__), "..", "include", "srmi.h")).read()
+    defs = {m.group(1): int(m.group(2), 0) for m in re.finditer(r"^#define\s+SRMI_(\w+)\s+(-?(?:0x[0-9a-fA-F]+|\d+))\b", hdr, re.M)}
+    both = [k for k in defs if hasattr(L, k) and isinstance(getattr(L, k), int)]
+    assert len(both) >= 15 and "ACT_ADD_RELU" in both
+    for k in both:
+        assert getattr(L, k) == defs[k], k
+
+
+def test_add_relu_kernel_selection():
+    # the activation that follows the residual (Res-U-SRGAN/untitled0.py:67-72) is served by the K-chunked bf16 kernel
+    # for 3x3 convs and by the generic kernel otherwise; the 64-channel tiles and the thin kernel decline it
+    d = Fn.make_desc(2, 16, 16, 64, 64, 3, in_dtype=L.BF16, out_dtype=L.BF16, compute=L.COMPUTE_BF16, act=L.ACT_ADD_RELU)
+    assert L.kernel_name(d) == "cin_bf16"
+    d = Fn.make_desc(2, 16, 16, 64, 64, 1, in_dtype=L.BF16, out_dtype=L.BF16, compute=L.COMPUTE_BF16, act=L.ACT_ADD_RELU)
+    assert L.kernel_name(d) == "generic_f32"
+    d = Fn.make_desc(2, 16, 16, 64, 3, 3, in_dtype=L.BF16, out_dtype=L.F32, compute=L.COMPUTE_BF16, act=L.ACT_ADD_RELU)
+    assert L.kernel_name(d) == "generic_f32"
+    d = Fn.make_desc(2, 16, 16, 64, 64, 3, act=L.ACT_ADD_RELU + 1)
+    n = C.c_size_t(0)
+    assert L.load().srmi_conv2d_packed_weight_bytes(C.byref(d), C.byref(n)) != 0
