@@ -86,6 +86,14 @@ def _cin_cases(n, seed):
         if i % 4 == 1:
             case.update(residual=True)
         out.append(case)
+    g2 = np.random.default_rng(seed + 1000)        # the activation that follows the residual (own stream: keeps the cases above)
+    for i in range(4):
+        Cin, Cout = int(g2.choice([64, 128, 192, 384])), int(g2.choice([64, 128]))
+        case = dict(N=int(g2.integers(1, 3)), H=int(g2.integers(1, 30)), W=int(g2.integers(1, 150)), Cin=Cin, Cout=Cout,
+                    act=L.ACT_ADD_RELU, residual=i != 3)
+        if i == 1:
+            case.update(out_cs=3 * Cout, out_co=2 * Cout)
+        out.append(case)
     return out
 
 
