@@ -1,6 +1,7 @@
 #!/bin/bash
 # Ablation of conv_thin_kernel on the headline workload (investigation only): SRMI_DBG bits 2 = no MFMAs, 4 = no
-# activation math, 8 = no output stores.  Prints the kernel's per-launch time from bench.py's per-layer table.
+# activation math, 8 = no output stores; bits 23-25 = cache policy of its loads / stores (api.hip).  THIN_ABLATE="0 8 ..."
+# overrides the list of SRMI_DBG values.  Prints bench.py's per-layer times (ms per launch) and ms per step.
 set -e
 for d in ${THIN_ABLATE:-0 2 4 8 10 14}; do
   echo -n "SRMI_DBG=$d  "
