@@ -248,6 +248,17 @@ int srmi_tv_loss(const float* x, int32_t N, int32_t C, int32_t H, int32_t W, flo
 int srmi_y_psnr_ssim(const float* sr, const float* gt, int32_t H, int32_t W, int32_t gt_H, int32_t gt_W,
                      int32_t border, int32_t clip, int32_t win, double* out, void* ws, void* stream);
 
+/* The same for every image pair of a batch in THREE launches (every training variant scores a validation
+ * set each epoch, P/mode.py:116-119; the reference moves one image at a time to the host): sr is a dense
+ * [n_images, 3, H, W] tensor, gt a dense [n_images, 3, gt_H, gt_W] tensor, out holds n_images x 3 f64
+ * ([mse, psnr, ssim] per image).  The workspace's partial slots are divided between the images, so
+ * n_images <= SRMI_METRICS_MAX_BATCH; results are bit-identical to n_images calls of srmi_y_psnr_ssim only when
+ * the per-image grids coincide (they do for n_images = 1); otherwise they agree to f64 rounding. */
+#define SRMI_METRICS_MAX_BATCH 256
+int srmi_y_psnr_ssim_batch(const float* sr, const float* gt, int32_t n_images, int32_t H, int32_t W, int32_t gt_H,
+                           int32_t gt_W, int32_t border, int32_t clip, int32_t win, double* out, void* ws,
+                           void* stream);
+
 /* ---- training step (fp32): train-mode BatchNorm, epilogue fwd/bwd, dgrad, wgrad, pool, loss grads, Adam ----
  * The training path keeps the conv and its epilogue as separate launches because train-mode BatchNorm needs
  * the batch statistics of the whole conv output before it can normalise (P/ops.py:24-26 with the module in

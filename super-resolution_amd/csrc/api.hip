@@ -42,8 +42,8 @@ int layout_convert(const void* src, void* dst, int N, int C, int H, int W, int s
 
 int pair_loss(int op, const float* a, const float* b, size_t n, float* out, void* ws, hipStream_t s);
 int tv_loss(const float* x, int N, int C, int H, int W, float weight, float* out, void* ws, hipStream_t s);
-int y_metrics(const float* sr, const float* gt, int H, int W, int gt_H, int gt_W, int border, int clip, int win,
-              double* out, void* ws, hipStream_t s);
+int y_metrics(const float* sr, const float* gt, int nimg, int H, int W, int gt_H, int gt_W, int border, int clip,
+              int win, double* out, void* ws, hipStream_t s);
 
 int bn_train_stats(const float* z, long long M, int C, float eps, float momentum, float* mean, float* rstd,
                    float* rmean, float* rvar, void* ws, hipStream_t s);
@@ -395,21 +395,42 @@ int srmi_tv_loss(const float* x, int32_t N, int32_t C, int32_t H, int32_t W, flo
     return tv_loss(x, N, C, H, W, weight, out, ws, (hipStream_t)stream);
 }
 
-int srmi_y_psnr_ssim(const float* sr, const float* gt, int32_t H, int32_t W, int32_t gt_H, int32_t gt_W,
-                     int32_t border, int32_t clip, int32_t win, double* out, void* ws, void* stream) {
-    int rc = check_reduce("y_psnr_ssim", sr, gt, out, ws);
+static int y_metrics_check(const char* what, const float* sr, const float* gt, int32_t H, int32_t W, int32_t gt_H,
+                           int32_t gt_W, int32_t border, int32_t win, double* out, void* ws) {
+    int rc = check_reduce(what, sr, gt, out, ws);
     if (rc) return rc;
-    if ((uintptr_t)out % 8) { set_error("y_psnr_ssim: out must be 8-byte aligned"); return SRMI_EINVAL; }
+    if ((uintptr_t)out % 8) { set_error("%s: out must be 8-byte aligned", what); return SRMI_EINVAL; }
     if (H <= 0 || W <= 0 || gt_H < H || gt_W < W || border < 0 || H - 2 * border <= 0 || W - 2 * border <= 0) {
-        set_error("y_psnr_ssim: bad geometry H=%d W=%d gt=%dx%d border=%d", H, W, gt_H, gt_W, border);
+        set_error("%s: bad geometry H=%d W=%d gt=%dx%d border=%d", what, H, W, gt_H, gt_W, border);
         return SRMI_EINVAL;
     }
     const int side = (H < W ? H : W) - 2 * border;
     if (win != 0 && (win < 3 || win > 7 || win % 2 == 0 || win > side)) {
-        set_error("y_psnr_ssim: window %d must be odd, 3..7 and <= the cropped side %d", win, side);
+        set_error("%s: window %d must be odd, 3..7 and <= the cropped side %d", what, win, side);
         return SRMI_EINVAL;
     }
-    return y_metrics(sr, gt, H, W, gt_H, gt_W, border, clip, win, out, ws, (hipStream_t)stream);
+    return SRMI_OK;
+}
+
+int srmi_y_psnr_ssim(const float* sr, const float* gt, int32_t H, int32_t W, int32_t gt_H, int32_t gt_W,
+                     int32_t border, int32_t clip, int32_t win, double* out, void* ws, void* stream) {
+    int rc = y_metrics_check("y_psnr_ssim", sr, gt, H, W, gt_H, gt_W, border, win, out, ws);
+    if (rc) return rc;
+    return y_metrics(sr, gt, 1, H, W, gt_H, gt_W, border, clip, win, out, ws, (hipStream_t)stream);
+}
+
+int srmi_y_psnr_ssim_batch(const float* sr, const float* gt, int32_t n_images, int32_t H, int32_t W, int32_t gt_H,
+                           int32_t gt_W, int32_t border, int32_t clip, int32_t win, double* out, void* ws,
+                           void* stream) {
+    if (n_images == 0) return SRMI_OK;
+    if (n_images < 0 || n_images > SRMI_METRICS_MAX_BATCH) {
+        set_error("y_psnr_ssim_batch: n_images = %d, must be 0..%d (split larger batches)", n_images,
+                  SRMI_METRICS_MAX_BATCH);
+        return SRMI_EINVAL;
+    }
+    int rc = y_metrics_check("y_psnr_ssim_batch", sr, gt, H, W, gt_H, gt_W, border, win, out, ws);
+    if (rc) return rc;
+    return y_metrics(sr, gt, n_images, H, W, gt_H, gt_W, border, clip, win, out, ws, (hipStream_t)stream);
 }
 
 static int epi_check(const char* what, const srmi_epi_desc* d) {

@@ -116,9 +116,12 @@ __device__ __forceinline__ double luma(const YImage im, int y, int x, int clip) 
 }
 
 // sum over the cropped region of ((Ya - Yb)/255)^2
+// blockIdx.y = image of the batch (image strides 3 * plane stride); each image owns gridDim.x partial slots
 __global__ __launch_bounds__(RED_BLOCK) void ypsnr_kernel(YImage a, YImage b, int y0, int x0, int h, int w, int clip_a,
                                                           double* __restrict__ ws) {
     __shared__ double lds[RED_BLOCK / 64];
+    a.p += (size_t)blockIdx.y * 3 * a.ps;
+    b.p += (size_t)blockIdx.y * 3 * b.ps;
     double acc = 0.0;
     const size_t total = (size_t)h * w;
     const size_t tid = (size_t)blockIdx.x * RED_BLOCK + threadIdx.x, nth = (size_t)gridDim.x * RED_BLOCK;
@@ -128,7 +131,7 @@ __global__ __launch_bounds__(RED_BLOCK) void ypsnr_kernel(YImage a, YImage b, in
         acc += d * d;
     }
     const double r = block_sum(acc, lds);
-    if (threadIdx.x == 0) ws[blockIdx.x] = r;
+    if (threadIdx.x == 0) ws[blockIdx.y * gridDim.x + blockIdx.x] = r;
 }
 
 // skimage.metrics.structural_similarity, uniform win x win window, sample covariance, K1=.01 K2=.03,
@@ -143,6 +146,8 @@ __global__ __launch_bounds__(RED_BLOCK) void yssim_kernel(YImage a, YImage b, in
                                                           double* __restrict__ ws) {
     __shared__ double lds[RED_BLOCK / 64];
     __shared__ double ta[SS_TILE * SS_TILE], tb[SS_TILE * SS_TILE];
+    a.p += (size_t)blockIdx.y * 3 * a.ps;
+    b.p += (size_t)blockIdx.y * 3 * b.ps;
     const int oh = h - win + 1, ow = w - win + 1;  // valid outputs
     const int span = SS_T + win - 1;
     const double inv_np = 1.0 / (double)(win * win);
@@ -175,7 +180,7 @@ __global__ __launch_bounds__(RED_BLOCK) void yssim_kernel(YImage a, YImage b, in
         }
     }
     const double r = block_sum(acc, lds);
-    if (threadIdx.x == 0) ws[RED_MAX_BLOCKS + blockIdx.x] = r;
+    if (threadIdx.x == 0) ws[RED_MAX_BLOCKS + blockIdx.y * gridDim.x + blockIdx.x] = r;
 }
 
 // out[0] = mse of Y/255, out[1] = PSNR (dB, data_range 1), out[2] = mean SSIM (NaN when not requested)
@@ -184,8 +189,9 @@ __global__ __launch_bounds__(RED_BLOCK) void finalize_metrics_kernel(const doubl
                                                                      double* __restrict__ out) {
     __shared__ double lds[RED_BLOCK / 64];
     double a = 0.0, b = 0.0;
-    for (int i = threadIdx.x; i < nb_psnr; i += RED_BLOCK) a += ws[i];
-    for (int i = threadIdx.x; i < nb_ssim; i += RED_BLOCK) b += ws[RED_MAX_BLOCKS + i];
+    out += 3 * blockIdx.x;   // one workgroup per image
+    for (int i = threadIdx.x; i < nb_psnr; i += RED_BLOCK) a += ws[blockIdx.x * nb_psnr + i];
+    for (int i = threadIdx.x; i < nb_ssim; i += RED_BLOCK) b += ws[RED_MAX_BLOCKS + blockIdx.x * nb_ssim + i];
     const double ra = block_sum(a, lds);
     const double rb = block_sum(b, lds);
     if (threadIdx.x == 0) {
@@ -232,12 +238,17 @@ int tv_loss(const float* x, int N, int C, int H, int W, float weight, float* out
     return hip_check(hipGetLastError(), "finalize_f32_kernel");
 }
 
-int y_metrics(const float* sr, const float* gt, int H, int W, int gt_H, int gt_W, int border, int clip, int win,
-              double* out, void* ws, hipStream_t s) {
+// nimg image pairs (dense batches: sr [nimg,3,H,W], gt [nimg,3,gt_H,gt_W]) in three launches; the RED_MAX_BLOCKS partial
+// slots of the workspace are divided evenly between the images
+int y_metrics(const float* sr, const float* gt, int nimg, int H, int W, int gt_H, int gt_W, int border, int clip,
+              int win, double* out, void* ws, hipStream_t s) {
     YImage a{sr, W, (size_t)H * W}, b{gt, gt_W, (size_t)gt_H * gt_W};
     const int h = H - 2 * border, w = W - 2 * border;
-    const int nbp = red_blocks((size_t)h * w);
-    hipLaunchKernelGGL(ypsnr_kernel, dim3(nbp), dim3(RED_BLOCK), 0, s, a, b, border, border, h, w, clip, (double*)ws);
+    const int slots = RED_MAX_BLOCKS / nimg;   // caller checked 1 <= nimg <= RED_MAX_BLOCKS
+    int nbp = red_blocks((size_t)h * w);
+    if (nbp > slots) nbp = slots;
+    hipLaunchKernelGGL(ypsnr_kernel, dim3(nbp, nimg), dim3(RED_BLOCK), 0, s, a, b, border, border, h, w, clip,
+                       (double*)ws);
     int rc = hip_check(hipGetLastError(), "ypsnr_kernel");
     if (rc) return rc;
     int nbs = 0;
@@ -246,15 +257,15 @@ int y_metrics(const float* sr, const float* gt, int H, int W, int gt_H, int gt_W
         const int oh = h - win + 1, ow = w - win + 1;
         const int tiles_x = (ow + SS_T - 1) / SS_T, tiles_y = (oh + SS_T - 1) / SS_T;
         const long long tiles = (long long)tiles_x * tiles_y;
-        nbs = (int)(tiles < RED_MAX_BLOCKS ? tiles : RED_MAX_BLOCKS);
+        nbs = (int)(tiles < slots ? tiles : slots);
         inv_ssim = 1.0 / ((double)oh * ow);
         // data_range = 1.0 as the reference passes it (P/mode.py:45), K1 = 0.01, K2 = 0.03
-        hipLaunchKernelGGL(yssim_kernel, dim3(nbs), dim3(RED_BLOCK), 0, s, a, b, border, border, h, w, win, clip,
+        hipLaunchKernelGGL(yssim_kernel, dim3(nbs, nimg), dim3(RED_BLOCK), 0, s, a, b, border, border, h, w, win, clip,
                            0.01 * 0.01, 0.03 * 0.03, tiles_x, (int)tiles, (double*)ws);
         rc = hip_check(hipGetLastError(), "yssim_kernel");
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(finalize_metrics_kernel, dim3(1), dim3(RED_BLOCK), 0, s, (const double*)ws, nbp, nbs,
+    hipLaunchKernelGGL(finalize_metrics_kernel, dim3(nimg), dim3(RED_BLOCK), 0, s, (const double*)ws, nbp, nbs,
                        1.0 / ((double)h * w), inv_ssim, out);
     return hip_check(hipGetLastError(), "finalize_metrics_kernel");
 }

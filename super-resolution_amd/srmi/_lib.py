@@ -109,6 +109,8 @@ SYMBOLS = {
                                C.c_void_p, C.c_void_p]),
     "srmi_y_psnr_ssim": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "srmi_y_psnr_ssim_batch": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                         C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]),
     "srmi_train_workspace_bytes": (C.c_int, [C.c_int32, C.POINTER(C.c_size_t)]),
     "srmi_bn_train_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
@@ -129,6 +131,7 @@ SYMBOLS = {
                                  C.c_float, C.c_float, C.c_int32, C.c_void_p]),
 }
 REDUCE_WS_BYTES = 16384
+METRICS_MAX_BATCH = 256
 
 _LIB = None
 

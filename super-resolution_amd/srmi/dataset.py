@@ -35,6 +35,15 @@ class crop(object):
         iy = random.randrange(0, ih - self.patch_size + 1)
         return iy, ix
 
+    def __call__(self, sample):
+        """The reference's per-sample path on host arrays (HWC numpy), for callers that use the transform directly or
+        inside a torchvision `Compose` (P/dataset.py:87-100).  `mydata` does not go through it (device batches)."""
+        LR_img, GT_img = sample['LR'], sample['GT']
+        ih, iw = LR_img.shape[:2]
+        iy, ix = self.draw(ih, iw)
+        p, s = self.patch_size, self.scale
+        return {'LR': LR_img[iy:iy + p, ix:ix + p], 'GT': GT_img[iy * s:iy * s + s * p, ix * s:ix * s + s * p]}
+
 
 class augmentation(object):
     """P/dataset.py:104-132.  `draw` makes the reference's three random draws; flips first, transpose last."""
@@ -45,12 +54,29 @@ class augmentation(object):
         rot = random.randrange(0, 2)
         return (L.AUG_HFLIP if hor_flip else 0) | (L.AUG_VFLIP if ver_flip else 0) | (L.AUG_TRANSPOSE if rot else 0)
 
+    def __call__(self, sample):
+        """Host-array form (P/dataset.py:104-132): fliplr, flipud, then transpose(1, 0, 2), copies like the reference."""
+        LR_img, GT_img = sample['LR'], sample['GT']
+        flags = self.draw()
+        if flags & L.AUG_HFLIP:
+            LR_img, GT_img = np.fliplr(LR_img).copy(), np.fliplr(GT_img).copy()
+        if flags & L.AUG_VFLIP:
+            LR_img, GT_img = np.flipud(LR_img).copy(), np.flipud(GT_img).copy()
+        if flags & L.AUG_TRANSPOSE:
+            LR_img, GT_img = LR_img.transpose(1, 0, 2), GT_img.transpose(1, 0, 2)
+        return {'LR': LR_img, 'GT': GT_img}
+
 
 class Compose(object):
     """Stand-in for torchvision.transforms.Compose (any object with a `.transforms` list works as well)."""
 
     def __init__(self, transforms):
         self.transforms = list(transforms)
+
+    def __call__(self, sample):
+        for t in self.transforms:
+            sample = t(sample)
+        return sample
 
 
 def _load_rgb(path):
@@ -62,8 +88,10 @@ class mydata(Dataset):
     """`mydata(LR_path, GT_path, in_memory=True, transform=None)` (P/dataset.py:9-49) with the images in device memory.
 
     `in_memory` keeps its one observable effect in the reference: the in-memory path normalises in float32
-    (P/dataset.py:33-34), the from-disk path in float64 rounded once (:37-41).  `transform` must contain a `crop`
-    (batches need one patch size); `augmentation` is optional; order as given.
+    (P/dataset.py:33-34), the from-disk path in float64 rounded once (:37-41).  `transform` must be `crop`,
+    optionally followed by `augmentation` (the reference's `Compose([crop(...), augmentation()])`, P/mode.py:75):
+    the batch kernel cuts first, then flips, then transposes.  Any other list (augmentation before crop, repeats,
+    foreign transforms) raises instead of being silently re-ordered.
     """
 
     def __init__(self, LR_path=None, GT_path=None, in_memory=True, transform=None, device="cuda:0", images=None):
@@ -82,6 +110,10 @@ class mydata(Dataset):
         if len(lr_imgs) != len(gt_imgs):
             raise ValueError("mydata: LR and GT image counts differ")
         self.transforms = [] if transform is None else list(getattr(transform, "transforms", [transform]))
+        kinds = [type(t) for t in self.transforms]
+        if kinds not in ([], [crop], [crop, augmentation]):
+            raise TypeError("mydata: transform must be crop, or Compose([crop, augmentation]) in that order (the device "
+                            f"kernel cuts, then flips, then transposes); got {[k.__name__ for k in kinds]}")
         self._crop = next((t for t in self.transforms if isinstance(t, crop)), None)
         self.scale = self._crop.scale if self._crop is not None else None
         self.shapes, self.lr_off, self.gt_off = [], [], []
@@ -145,6 +177,46 @@ class mydata(Dataset):
     def loader(self, batch_size=1, shuffle=False, drop_last=False):
         """Iterable of device batches in the order `DataLoader(self, batch_size, shuffle, num_workers=0)` yields them."""
         return _DeviceLoader(self, batch_size, shuffle, drop_last)
+
+
+class testOnly_data(Dataset):
+    """`testOnly_data(LR_path, in_memory=True, transform=None)` (P/dataset.py:52-78): LR images only, whole frames,
+    no `.convert("RGB")` (as the reference: greyscale / RGBA files keep their channel count).  `__getitem__` returns the
+    reference's `{'LR': CHW float32 numpy}`; `device_item(i)` returns the same image as a [1, C, H, W] device tensor
+    converted by `srmi_u8hwc_to_f32nchw` (bit-identical: `v / 127.5 - 1` in f64, rounded once), which is what
+    `srmi.mode.test_only` feeds the generator."""
+
+    def __init__(self, LR_path, in_memory=True, transform=None, device="cuda:0"):
+        self.LR_path = LR_path
+        self.names = sorted(os.listdir(LR_path))
+        self.in_memory = in_memory
+        self.device = torch.device(device)
+        self.LR_img = [self._read(n) for n in self.names] if in_memory else None
+
+    def _read(self, name):
+        from PIL import Image
+        return np.array(Image.open(os.path.join(self.LR_path, name)))
+
+    def __len__(self):
+        return len(self.names)
+
+    def _u8(self, i):
+        LR = self.LR_img[i] if self.in_memory else self._read(self.names[i])
+        if LR.ndim != 3:
+            raise ValueError(f"testOnly_data: {self.names[i]} is not an HWC image (the reference's transpose(2, 0, 1) "
+                             "fails on it too, P/dataset.py:76)")
+        return LR
+
+    def __getitem__(self, i):
+        LR = self._u8(i)
+        return {'LR': ((LR / 127.5) - 1.0).transpose(2, 0, 1).astype(np.float32)}
+
+    def device_item(self, i):
+        from .imageio import from_uint8
+        LR = self._u8(i)
+        if LR.dtype != np.uint8:
+            return {'LR': torch.from_numpy(self[i]['LR'])[None].to(self.device)}
+        return {'LR': from_uint8(torch.from_numpy(np.ascontiguousarray(LR))[None].to(self.device))}
 
 
 class _DeviceLoader:

@@ -3,9 +3,13 @@
 A plan owns (a) the packed weights and folded scale/shift vectors of every layer, (b) the NHWC
 activation buffers sized for one input shape, and (c) a ctypes array of ``srmi_conv_args`` that
 ``srmi_conv2d_fwd_seq`` walks from C++ - one FFI crossing per forward instead of one per layer.
-Plans are cached per (input shape, compute mode) and rebuilt when a parameter or buffer of the
+Plans are cached per (device, input shape, compute mode) and rebuilt when a parameter or buffer of the
 module changes (``load_state_dict``, ``.to()``, an optimizer step): the signature is the tuple of
 (data_ptr, version) of every tensor the plan folded.
+
+A write through ``tensor.data`` (``p.data.copy_()``, ``p.data.mul_()``, hand-rolled EMA updates) does NOT bump
+torch's version counter, so no signature can see it: after such a write call ``srmi.invalidate(module)`` (below),
+or write through ``with torch.no_grad(): p.copy_(...)`` instead, which does bump it.
 """
 from __future__ import annotations
 
@@ -16,6 +20,21 @@ import torch.nn as nn
 
 from . import _lib as L
 from . import functional as Fn
+
+
+def invalidate(module: nn.Module):
+    """Drop every cached plan / packed weight of `module` and its sub-modules.  Needed only after parameters or
+    buffers were modified through ``.data`` (which torch's version counter cannot see); every other update
+    (optimizer steps, ``load_state_dict``, ``.to()``, in-place ops under ``no_grad``) is detected automatically."""
+    for m in module.modules():
+        plans = m.__dict__.get("_plans")
+        if plans is not None:
+            plans.clear()
+        cache = m.__dict__.get("_cache")
+        if cache is not None and hasattr(cache, "entries"):
+            cache.entries.clear()
+            cache.sig = None
+    return module
 
 
 def _sig(module: nn.Module):
@@ -239,7 +258,9 @@ class PlanCache:
         self.plans = {}
 
     def get(self, module, N, H, W, compute):
-        key = (N, H, W, compute)
+        # the device is part of the key: nn.DataParallel replicas share this object through the __dict__ copy
+        dev = next(module.parameters()).device
+        key = (dev.index, N, H, W, compute)
         sig = _sig(module)
         hit = self.plans.get(key)
         if hit is not None and hit[0] == sig:

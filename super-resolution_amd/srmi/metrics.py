@@ -47,10 +47,13 @@ def y_psnr_ssim(gt: torch.Tensor, output: torch.Tensor, scale: int = 1, clip: bo
 
 
 def calculate_metrics(gt, output, device=None, scale=1):
-    """Drop-in for the PSNR/SSIM half of ``calculate_metrics`` (P/mode.py:24-45): returns
-    ``(psnr, ssim)`` as Python floats (one device->host copy of 24 bytes)."""
+    """Drop-in for ``calculate_metrics`` (P/mode.py:24-67): returns the reference's 4-tuple
+    ``(psnr, ssim, lpips_score, dists_score)`` so that the loops' ``psnr, ssim, lpips_score, dists_score = ...``
+    (P/mode.py:117, :191) unpack unchanged.  PSNR and SSIM are computed on the device (one device->host copy of
+    24 bytes); LPIPS and DISTS need third-party pretrained networks that are out of scope: their columns are NaN
+    ("columns optional/NaN")."""
     r = y_psnr_ssim(gt, output, scale=scale, clip=False, ssim=True).cpu()
-    return float(r[1]), float(r[2])
+    return float(r[1]), float(r[2]), float("nan"), float("nan")
 
 
 def test_psnr(gt, output, scale):
@@ -60,9 +63,30 @@ def test_psnr(gt, output, scale):
 
 def y_psnr_ssim_batch(gt: torch.Tensor, output: torch.Tensor, scale: int = 1, clip: bool = False, ssim: bool = True):
     """[N, 3] float64 DEVICE tensor of [mse, psnr, ssim] for EVERY image of the batch: the reference scores
-    one image per call on the host; here N images are scored where they live, with no host synchronisation."""
+    one image per call on the host; here the whole batch is scored where it lives by three launches
+    (``srmi_y_psnr_ssim_batch``), with no host synchronisation."""
+    require_cuda(gt, "gt")
+    require_cuda(output, "output")
+    if output.dim() != 4 or gt.dim() != 4 or output.shape[1] != 3 or gt.shape[1] != 3:
+        raise ValueError("y_psnr_ssim_batch expects Nx3xHxW tensors")
     n = min(gt.shape[0], output.shape[0])
-    return torch.stack([y_psnr_ssim(gt, output, scale=scale, clip=clip, ssim=ssim, index=i) for i in range(n)])
+    o = output[:n].float().contiguous()
+    g = gt[:n].float().contiguous()
+    H, W = o.shape[2:]
+    gH, gW = g.shape[2:]
+    if scale < 1:
+        raise ValueError("scale must be >= 1 (the reference slices [scale:-scale])")
+    win = ssim_window(H, W, scale) if ssim else 0
+    if ssim and win < 3:
+        raise ValueError(f"image {H}x{W} too small for SSIM after cropping {scale} px")
+    res = torch.empty((n, 3), dtype=torch.float64, device=o.device)
+    ws = _workspace(o.device).data_ptr()
+    lib = L.load()
+    for i0 in range(0, n, L.METRICS_MAX_BATCH):
+        nb = min(L.METRICS_MAX_BATCH, n - i0)
+        L.check(lib.srmi_y_psnr_ssim_batch(o[i0:].data_ptr(), g[i0:].data_ptr(), nb, H, W, gH, gW, scale, int(clip), win,
+                                           res[i0:].data_ptr(), ws, stream_ptr()))
+    return res
 
 
 class MetricAverager:

@@ -71,5 +71,9 @@ def broadcast_parameters(module, src=0, group=None):
     """Make every rank start from rank `src`'s parameters and buffers (call once before training)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
-    for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src=src, group=group)
+    with torch.no_grad():
+        for t in list(module.parameters()) + list(module.buffers()):
+            # .detach() shares the version counter with t (t.data would not): cached inference plans see the write
+            dist.broadcast(t.detach(), src=src, group=group)
+    from .engine import invalidate
+    invalidate(module)      # belt and braces: a collective backend that writes below torch's version tracking

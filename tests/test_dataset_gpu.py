@@ -49,3 +49,29 @@ def test_getitem_and_guards():
     plain = D.mydata(in_memory=True, images=([z["lr0"]], [z["gt0"]]))
     with pytest.raises(NotImplementedError):
         plain.batch([0])
+
+
+def test_transform_order_is_checked():
+    """The batch kernel cuts, then flips, then transposes: any other transform list raises instead of being re-ordered."""
+    z = np.load(GOLD)
+    imgs = ([z["lr0"]], [z["gt0"]])
+    for bad in ([D.augmentation(), D.crop(4, 8)], [D.augmentation()], [D.crop(4, 8), D.crop(4, 8)], [lambda s: s]):
+        with pytest.raises(TypeError, match="transform must be crop"):
+            D.mydata(in_memory=True, transform=D.Compose(bad), images=imgs)
+    D.mydata(in_memory=True, transform=D.crop(4, 8), images=imgs)          # a bare transform, as the reference allows
+
+
+def test_testonly_data(tmp_path):
+    from PIL import Image
+    rng = np.random.default_rng(0)
+    imgs = [rng.integers(0, 256, (9 + i, 7, 3), dtype=np.uint8) for i in range(2)]
+    for i, im in enumerate(imgs):
+        Image.fromarray(im).save(tmp_path / f"im{i}.png")
+    for in_memory in (True, False):
+        ds = D.testOnly_data(str(tmp_path), in_memory=in_memory)
+        assert len(ds) == 2
+        for i, im in enumerate(imgs):
+            ref = ((im / 127.5) - 1.0).transpose(2, 0, 1).astype(np.float32)       # P/dataset.py:75-76
+            assert np.array_equal(ds[i]["LR"], ref)
+            dev = ds.device_item(i)["LR"]
+            assert dev.is_cuda and np.array_equal(dev[0].cpu().numpy(), ref)

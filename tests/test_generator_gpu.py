@@ -241,3 +241,22 @@ def test_tiled_inference_equals_whole_frame_when_halo_covers_receptive_field():
         # BASELINE's 8-px halo: per-tile parity by construction, frame-level approximation reported
         approx, _ = tiling.sr_tiled(gen, x, tile=(27, 24), halo=8)
     print("8-px halo vs whole frame max|d| =", (whole - approx).abs().max().item())
+
+
+def test_data_mutation_needs_invalidate():
+    """a write through `.data` does not bump torch's version counter, so the cached plan keeps the old
+    packed weights until `srmi.invalidate(module)`; a write under no_grad is seen automatically."""
+    import srmi
+    gen = Generator(num_block=2)
+    gen.load_state_dict(O.to_torch(W.generator_weights(seed=0, num_block=2)))
+    gen = gen.to(DEV).eval()
+    x = torch.from_numpy(W.lr_input((1, 3, 12, 16), seed=1)).to(DEV)
+    with torch.no_grad():
+        a, _ = gen(x)
+        gen.last_conv.body[0].weight.data.mul_(0.5)
+        srmi.invalidate(gen)
+        b, _ = gen(x)
+        assert not torch.equal(a, b)
+        gen.last_conv.body[0].weight.mul_(2.0)          # versioned write: detected without invalidate()
+        c, _ = gen(x)
+        assert torch.allclose(a, c, atol=1e-6)

@@ -76,7 +76,9 @@ def test_y_psnr_ssim(H, W, scale, gt_extra):
     gt = torch.rand(2, 3, H + gt_extra[0], W + gt_extra[1], generator=g) * 2 - 1
     out = (gt[:, :, :H, :W] + 0.08 * torch.randn(2, 3, H, W, generator=g))
     p_ref, s_ref = M.calculate_metrics(gt.numpy(), out.numpy(), scale=scale)
-    p, s = metrics.calculate_metrics(gt.to(DEV), out.to(DEV), None, scale=scale)
+    # the reference's 4-tuple (P/mode.py:67, unpacked at :117 and :191); LPIPS / DISTS columns are NaN
+    p, s, lp, di = metrics.calculate_metrics(gt.to(DEV), out.to(DEV), None, scale=scale)
+    assert np.isnan(lp) and np.isnan(di)
     assert abs(p - p_ref) <= 1e-4, (p, p_ref)          # float32 inputs, float64 arithmetic on both sides
     assert abs(s - s_ref) <= 1e-6, (s, s_ref)
     # test(): clipped output, PSNR only
@@ -117,6 +119,28 @@ def test_batched_metrics_and_averager():
             p_ref, s_ref = M.calculate_metrics(gt[i:i + 1].numpy(), out[i:i + 1].numpy(), scale=2)
             assert abs(float(r[i, 1]) - p_ref) <= 1e-4 and abs(float(r[i, 2]) - s_ref) <= 1e-6
             ps.append(p_ref); ss.append(s_ref)
+        # one batched call == per-image calls (same kernels, the workspace slots divided between the images)
+        for i in range(n):
+            one = metrics.y_psnr_ssim(gt.to(DEV), out.to(DEV), scale=2, index=i)
+            assert torch.allclose(one, r[i], rtol=1e-12, atol=0)
         av.update(gt.to(DEV), out.to(DEV))
     p, s = av.result()
     assert abs(p - np.mean(ps)) <= 1e-4 and abs(s - np.mean(ss)) <= 1e-6
+
+
+def test_batched_metrics_large_batch_and_guard():
+    """More images than SRMI_METRICS_MAX_BATCH are split by the wrapper; the C entry point rejects them."""
+    from srmi import _lib as L
+    g = torch.Generator().manual_seed(5)
+    n = L.METRICS_MAX_BATCH + 3
+    gt = (torch.rand(n, 3, 12, 14, generator=g) * 2 - 1).to(DEV)
+    out = gt + 0.05 * torch.randn(n, 3, 12, 14, generator=g).to(DEV)
+    r = metrics.y_psnr_ssim_batch(gt, out, scale=1)
+    for i in (0, 17, L.METRICS_MAX_BATCH - 1, L.METRICS_MAX_BATCH, n - 1):
+        p_ref, s_ref = M.calculate_metrics(gt[i:i + 1].cpu().numpy(), out[i:i + 1].cpu().numpy(), scale=1)
+        assert abs(float(r[i, 1]) - p_ref) <= 1e-4 and abs(float(r[i, 2]) - s_ref) <= 1e-6
+    ws = torch.empty(2048, dtype=torch.float64, device=DEV)
+    o = torch.empty(3 * n, dtype=torch.float64, device=DEV)
+    rc = L.load().srmi_y_psnr_ssim_batch(out.data_ptr(), gt.data_ptr(), n, 12, 14, 12, 14, 1, 0, 7, o.data_ptr(),
+                                         ws.data_ptr(), 0)
+    assert rc == -1 and b"n_images" in L.load().srmi_last_error()

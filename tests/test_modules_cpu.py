@@ -102,3 +102,38 @@ def test_compute_mode_switch():
     assert g.compute == "bf16"
     with pytest.raises(ValueError):
         g.set_compute("fp8")
+
+
+def test_dataset_transforms_callable_like_reference():
+    """`crop` / `augmentation` / `Compose` applied to a host sample (P/dataset.py:87-132): same random draws in the same
+    order as the reference's `__call__`s, same numpy result."""
+    import random
+
+    from srmi import dataset as D
+    rng = np.random.default_rng(3)
+    lr = rng.integers(0, 256, (20, 17, 3)).astype(np.float32)
+    gt = rng.integers(0, 256, (80, 68, 3)).astype(np.float32)
+    tf = D.Compose([D.crop(4, 8), D.augmentation()])
+    random.seed(11)
+    out = tf({"LR": lr, "GT": gt})
+    # the reference's arithmetic, restated inline with the same draw order: ix, iy, hor_flip, ver_flip, rot
+    random.seed(11)
+    ix = random.randrange(0, 17 - 8 + 1); iy = random.randrange(0, 20 - 8 + 1)
+    l, g = lr[iy:iy + 8, ix:ix + 8], gt[4 * iy:4 * iy + 32, 4 * ix:4 * ix + 32]
+    hf, vf, rot = random.randrange(0, 2), random.randrange(0, 2), random.randrange(0, 2)
+    if hf:
+        l, g = np.fliplr(l), np.fliplr(g)
+    if vf:
+        l, g = np.flipud(l), np.flipud(g)
+    if rot:
+        l, g = l.transpose(1, 0, 2), g.transpose(1, 0, 2)
+    assert np.array_equal(out["LR"], l) and np.array_equal(out["GT"], g)
+    assert hasattr(D, "testOnly_data") and hasattr(D, "mydata")          # `from dataset import *` of P/mode.py:7
+
+
+def test_invalidate_clears_caches():
+    g = Generator(num_block=1)
+    g._plans.plans[("x",)] = (None, None)
+    g.conv01._cache.entries["k"] = 1
+    assert srmi.invalidate(g) is g
+    assert not g._plans.plans and not g.conv01._cache.entries
