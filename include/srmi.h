@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SRMI_VERSION 100 /* 0.1.0 */
+#define SRMI_VERSION 110 /* 0.1.1: dgrad / wgrad take a workspace (deterministic split-K), no float atomics left */
 
 /* error codes */
 #define SRMI_OK 0
@@ -134,11 +134,12 @@ int srmi_conv2d_pack_weights(const srmi_conv_desc* d, const float* w_oihw, void*
 /* one fused conv (see srmi_conv_desc). */
 int srmi_conv2d_fwd(const srmi_conv_args* a, void* stream);
 
-/* Deterministic variant for the linear-epilogue f32 convs of the training path (scale == NULL, act NONE, no
+/* Workspace variant for the linear-epilogue f32 convs of the training path (scale == NULL, act NONE, no
  * residual): spatially small, deep layers are split along K to fill the chip; with a workspace of
  * srmi_conv2d_workspace_bytes(d) bytes the K slices are stored there and added in slice order (same input =>
- * same bits, which keeps every activation on the same side of its ReLU kink from run to run); srmi_conv2d_fwd
- * (no workspace) adds them with f32 atomics instead.  bytes = 0: the conv does not split, ws may be NULL. */
+ * same bits, which keeps every activation on the same side of its ReLU kink from run to run).  Without a
+ * workspace (srmi_conv2d_fwd, or ws == NULL / too small) the conv does not split: slower on such layers, same
+ * determinism.  The library contains NO floating-point atomics.  bytes = 0: the conv never splits. */
 int srmi_conv2d_workspace_bytes(const srmi_conv_desc* d, size_t* bytes);
 int srmi_conv2d_fwd_ws(const srmi_conv_args* a, void* ws, size_t ws_bytes, void* stream);
 
@@ -300,14 +301,24 @@ int srmi_epilogue_bwd(const srmi_epi_desc* d, const float* z, const float* dy, c
                       float* dsum2, float* dalpha, void* ws, void* stream);
 
 /* Input gradient of the conv described by `d` (geometry fields only; NHWC f32): dx[N,H,W,Cin] from
- * dz[N,Ho,Wo,Cout].  The weights are packed once per step by srmi_conv2d_dgrad_pack_weights. */
+ * dz[N,Ho,Wo,Cout].  The weights are packed once per parameter version by srmi_conv2d_dgrad_pack_weights.
+ * `ws` (16-byte aligned, srmi_conv2d_dgrad_workspace_bytes(d) bytes; may be NULL) lets spatially small, deep layers
+ * split K over the chip: the slices are stored and added in slice order.  Deterministic with or without it
+ * (same inputs => same bits; autograd of the reference's nn.Conv2d, P/mode.py:105, :160, :178). */
 int srmi_conv2d_dgrad_packed_weight_bytes(const srmi_conv_desc* d, size_t* bytes);
 int srmi_conv2d_dgrad_pack_weights(const srmi_conv_desc* d, const float* w_oihw, void* w_packed, void* stream);
-int srmi_conv2d_dgrad(const srmi_conv_desc* d, const float* dz, const void* w_packed, float* dx, void* stream);
+int srmi_conv2d_dgrad_workspace_bytes(const srmi_conv_desc* d, size_t* bytes);
+int srmi_conv2d_dgrad(const srmi_conv_desc* d, const float* dz, const void* w_packed, float* dx, void* ws,
+                      size_t ws_bytes, void* stream);
 
 /* Weight gradient: dw (OIHW f32, the nn.Conv2d.weight.grad layout) = sum over pixels of dz (x) x; dw is
- * overwritten.  x is NHWC f32 with d->in_cstride channels per pixel (0 = Cin). */
-int srmi_conv2d_wgrad(const srmi_conv_desc* d, const float* x, const float* dz, float* dw, void* stream);
+ * overwritten.  x is NHWC f32 with d->in_cstride channels per pixel (0 = Cin).  The pixel sum is split over
+ * workgroups; with `ws` (16-byte aligned, srmi_conv2d_wgrad_workspace_bytes(d) bytes) each stores its partial tile
+ * there and a second launch adds them in a fixed order; with ws == NULL one workgroup owns each tile (slow on large
+ * maps).  Deterministic either way. */
+int srmi_conv2d_wgrad_workspace_bytes(const srmi_conv_desc* d, size_t* bytes);
+int srmi_conv2d_wgrad(const srmi_conv_desc* d, const float* x, const float* dz, float* dw, void* ws, size_t ws_bytes,
+                      void* stream);
 
 /* 2x2 stride-2 max pool, NHWC f32 (VGG19 features, P/vgg19.py:13-17); H, W are the INPUT size. */
 int srmi_maxpool2x2_fwd(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream);

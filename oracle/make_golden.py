@@ -325,6 +325,33 @@ def srgan_step_case(fname, num_block, batch, lr_hw, tv_coeff, wseed=0, xseed=31)
         _put(out, "after_g", name, v)
     for name, v in discriminator.state_dict().items():
         _put(out, "after_d", name, v)
+    # ---- the same iteration in float64 (oracle restatement, its own f64 Adam step for D): the yardstick that tells
+    # rounding-order effects (activation-kink flips, Adam's first step = lr * sign(grad)) from arithmetic errors.
+    # Tests require srmi's fp32 gradients to sit about as close to these as the reference's own fp32 gradients do.
+    f64 = lambda sd: {k: (v.double().clone().requires_grad_(True) if v.is_floating_point() and "running" not in k
+                          else (v.double().clone() if v.is_floating_point() else v.clone()))
+                      for k, v in O.to_torch(sd).items()}
+    g64, d64, v64 = f64(g_np), f64(d_np), {k: v.double() for k, v in O.to_torch(v_np).items()}
+    shared64 = g64["conv01.body.1.weight"]
+    for k in g64:
+        if k.endswith(".weight") and g64[k].shape == (1,):
+            g64[k] = shared64
+    d_part64, g_part64 = T_.srgan_losses(g64, d64, v64, lr.double(), gt.double(), num_block, {}, {}, vgg_rescale_coeff,
+                                         adv_coeff, tv_coeff, feat_layer)
+    d_part64().backward()
+    dnames = [n for n, _ in discriminator.named_parameters()]
+    for name in dnames:
+        _put(out, "dgrad64", name, d64[name].grad)
+    with torch.no_grad():
+        ps = [d64[n] for n in dnames]
+        gs = [d64[n].grad.clone() for n in dnames]
+        T_.adam_step(ps, gs, dict(step=0, m=[torch.zeros_like(p_) for p_ in ps], v=[torch.zeros_like(p_) for p_ in ps]))
+    for t in list(g64.values()) + list(d64.values()):
+        if t.grad is not None:
+            t.grad = None
+    g_part64()[0].backward()
+    for name, _ in generator.named_parameters():
+        _put(out, "ggrad64", name, g64[name].grad)
     for k in gstats:
         _check("G " + k[-28:], generator.state_dict()[k].double(), gstats[k].double(), tol=1e-5)
     for k in dstats:
@@ -390,5 +417,8 @@ if __name__ == "__main__":
     # gradients sit 0.5-3 % away from an fp64 run of the same graph, so nothing can be pinned to them.
     srgan_step_case("srgan_step_b8_lr16_tv0.npz", 2, 8, 16, 0.0)            # reference defaults (tv coeff 0, P/main.py:17)
     srgan_step_case("srgan_step_b8_lr16_tv.npz", 2, 8, 16, 2e-2, xseed=41)  # TV term switched on
+    # the reference's DEFAULT configuration (P/main.py:12,14,21: res_num 16, batch_size 16, patch_size 24;
+    # P/mode.py:128: Discriminator(patch_size=96)) = BASELINE config 3 per GPU
+    srgan_step_case("srgan_step_default_b16_lr24.npz", 16, 16, 24, 0.0, xseed=51)
     # restore the process-wide shared PReLU to its default for anyone importing after us
     print("done ->", GOLD)

@@ -61,10 +61,12 @@ int adam_step(float* param, const float* grad, float* m, float* v, size_t n, flo
 int tv_bwd(const float* x, const float* gout, int N, int C, int H, int W, float weight, float* dx, hipStream_t s);
 size_t generic_dgrad_packed_bytes(const srmi_conv_desc& d);
 int generic_dgrad_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s);
+size_t generic_dgrad_workspace_bytes(const srmi_conv_desc& d, const ConvGeom& g);
+size_t wgrad_workspace_bytes(const srmi_conv_desc& d, const ConvGeom& g);
 int generic_dgrad_launch(const srmi_conv_desc& d, const ConvGeom& g, const float* dz, const float* w_dgrad, float* dx,
-                         hipStream_t s);
+                         hipStream_t s, void* ws, size_t ws_bytes);
 int wgrad_launch(const srmi_conv_desc& d, const ConvGeom& g, const float* x, const float* dz, float* dw,
-                 hipStream_t s);
+                 hipStream_t s, void* ws, size_t ws_bytes);
 
 int u8_to_f32(const unsigned char* src, float* dst, int N, int H, int W, int C, hipStream_t s);
 int f32_to_u8(const float* src, unsigned char* dst, int N, int H, int W, int C, int clip, hipStream_t s);
@@ -514,30 +516,51 @@ int srmi_conv2d_dgrad_pack_weights(const srmi_conv_desc* d, const float* w_oihw,
     return generic_dgrad_pack(*d, w_oihw, w_packed, (hipStream_t)stream);
 }
 
-int srmi_conv2d_dgrad(const srmi_conv_desc* d, const float* dz, const void* w_packed, float* dx, void* stream) {
+int srmi_conv2d_dgrad_workspace_bytes(const srmi_conv_desc* d, size_t* bytes) {
+    ConvGeom g;
+    int rc = grad_geom("dgrad_workspace_bytes", d, &g);
+    if (rc) return rc;
+    if (!bytes) { set_error("dgrad_workspace_bytes: NULL argument"); return SRMI_EINVAL; }
+    *bytes = generic_dgrad_workspace_bytes(*d, g);
+    return SRMI_OK;
+}
+
+int srmi_conv2d_dgrad(const srmi_conv_desc* d, const float* dz, const void* w_packed, float* dx, void* ws,
+                      size_t ws_bytes, void* stream) {
     ConvGeom g;
     int rc = grad_geom("dgrad", d, &g);
     if (rc) return rc;
     if (d->in_cstride && d->in_cstride != d->Cin) { set_error("dgrad: dx must be dense"); return SRMI_EUNSUPPORTED; }
+    if (ws && ((uintptr_t)ws & 15)) { set_error("dgrad: workspace must be 16-byte aligned"); return SRMI_EINVAL; }
     if ((long long)d->N * d->H * d->W == 0) return SRMI_OK;
     if (!dz || !w_packed || !dx) { set_error("dgrad: NULL argument"); return SRMI_EINVAL; }
     if ((long long)d->N * g.Ho * g.Wo == 0)
         return hip_check(hipMemsetAsync(dx, 0, (size_t)d->N * d->H * d->W * d->Cin * sizeof(float), (hipStream_t)stream),
                          "dgrad memset");
-    return generic_dgrad_launch(*d, g, dz, (const float*)w_packed, dx, (hipStream_t)stream);
+    return generic_dgrad_launch(*d, g, dz, (const float*)w_packed, dx, (hipStream_t)stream, ws, ws ? ws_bytes : 0);
 }
 
-int srmi_conv2d_wgrad(const srmi_conv_desc* d, const float* x, const float* dz, float* dw, void* stream) {
+int srmi_conv2d_wgrad_workspace_bytes(const srmi_conv_desc* d, size_t* bytes) {
+    ConvGeom g;
+    int rc = grad_geom("wgrad_workspace_bytes", d, &g);
+    if (rc) return rc;
+    if (!bytes) { set_error("wgrad_workspace_bytes: NULL argument"); return SRMI_EINVAL; }
+    *bytes = wgrad_workspace_bytes(*d, g);
+    return SRMI_OK;
+}
+
+int srmi_conv2d_wgrad(const srmi_conv_desc* d, const float* x, const float* dz, float* dw, void* ws, size_t ws_bytes,
+                      void* stream) {
     ConvGeom g;
     int rc = grad_geom("wgrad", d, &g);
     if (rc) return rc;
     if (!dw) { set_error("wgrad: NULL dw"); return SRMI_EINVAL; }
-    rc = hip_check(hipMemsetAsync(dw, 0, (size_t)d->Cout * d->Cin * d->kh * d->kw * sizeof(float), (hipStream_t)stream),
-                   "wgrad memset");
-    if (rc) return rc;
-    if ((long long)d->N * g.Ho * g.Wo == 0) return SRMI_OK;
+    if (ws && ((uintptr_t)ws & 15)) { set_error("wgrad: workspace must be 16-byte aligned"); return SRMI_EINVAL; }
+    if ((long long)d->N * g.Ho * g.Wo == 0)     // no pixels: the gradient is zero (every other case overwrites all of dw)
+        return hip_check(hipMemsetAsync(dw, 0, (size_t)d->Cout * d->Cin * d->kh * d->kw * sizeof(float),
+                                        (hipStream_t)stream), "wgrad memset");
     if (!x || !dz) { set_error("wgrad: NULL argument"); return SRMI_EINVAL; }
-    return wgrad_launch(*d, g, x, dz, dw, (hipStream_t)stream);
+    return wgrad_launch(*d, g, x, dz, dw, (hipStream_t)stream, ws, ws ? ws_bytes : 0);
 }
 
 int srmi_maxpool2x2_fwd(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t C, void* stream) {

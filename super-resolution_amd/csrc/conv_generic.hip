@@ -25,9 +25,9 @@ struct GenericParams {
     int act; float act_param; int alpha_pc; int r; int dcr;
     int Cin_pad, Cout_pad, M;
     hipStream_t stream;
-    int ksplit;      // > 1: grid.z slices of K, partial sums added to a pre-zeroed f32 y (no activation / residual)
-    float* partial;  // ksplit > 1: when set, slice z STORES its partial tile at partial + z * partial_stride (same
-    size_t partial_stride;  // indexing as y) and generic_splitk_reduce_kernel adds the slices in index order: deterministic
+    int ksplit;      // > 1: grid.z slices of K (linear epilogue only: no scale / activation / residual)
+    float* partial;  // ksplit > 1: slice z STORES its partial tile at partial + z * partial_stride (same indexing
+    size_t partial_stride;  // as y) and generic_splitk_reduce_kernel adds the slices in index order: deterministic
     int transposed;  // dgrad: gather dz at (o + pad - k) / stride where divisible
 };
 
@@ -151,8 +151,7 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(GenericParams p) {
                 ridx = px * p.res_cs + c;
             }
             if (p.ksplit > 1) {
-                if (p.partial) p.partial[(size_t)blockIdx.z * p.partial_stride + oidx] = val;
-                else unsafeAtomicAdd((float*)p.y + oidx, val);
+                p.partial[(size_t)blockIdx.z * p.partial_stride + oidx] = val;
                 continue;
             }
             if (p.res) val += p.res_bf16 ? bf2f(((const bf16_t*)p.res)[ridx]) : ((const float*)p.res)[ridx];
@@ -311,17 +310,14 @@ static int generic_run(const GenericParams& p0) {
     const unsigned gy = p.Cout > 32 ? (unsigned)((p.Cout + 63) / 64) : 1u;
     // Split K when the pixel x channel tiling alone cannot fill 256 CUs (deep, spatially small layers: the
     // discriminator tail, VGG conv4/conv5, Linear layers, their dgrads).  Needs a linear epilogue with unit
-    // scale and a dense f32 output, which is what the training path asks for; partials meet in f32 atomics.
+    // scale and a dense f32 output, which is what the training path asks for, and a workspace: the slices are
+    // stored there and added in slice order, so the result is the same bits on every run.  There are NO float
+    // atomics in this file: without a (large enough) workspace the conv simply does not split.
     p.ksplit = generic_ksplit(p);
     const size_t out_elems = (size_t)p.N * p.Cf * p.Hf * p.Wf;
     if (p.ksplit > 1) {
-        if (p.partial && p.partial_stride >= out_elems * (size_t)p.ksplit) {
-            p.partial_stride = out_elems;            // deterministic: slices stored, then reduced in order
-        } else {
-            p.partial = nullptr;                     // no (or too small a) workspace: f32 atomics into a zeroed y
-            int rc = hip_check(hipMemsetAsync(p.y, 0, out_elems * sizeof(float), s), "split-K memset");
-            if (rc) return rc;
-        }
+        if (p.partial && p.partial_stride >= out_elems * (size_t)p.ksplit) p.partial_stride = out_elems;
+        else { p.ksplit = 1; p.partial = nullptr; }
     }
     dim3 grid(gx, gy, (unsigned)p.ksplit);
     if (p.Cout > 32) {
@@ -338,27 +334,47 @@ static int generic_run(const GenericParams& p0) {
     return hip_check(hipGetLastError(), "generic_splitk_reduce_kernel");
 }
 
+static void generic_dgrad_fill(GenericParams& p, const srmi_conv_desc& d, const ConvGeom& g);
+
+// bytes of workspace with which the dgrad of `d` splits K (0: it does not split)
+size_t generic_dgrad_workspace_bytes(const srmi_conv_desc& d, const ConvGeom& g) {
+    GenericParams p;
+    generic_dgrad_fill(p, d, g);
+    const long long M = (long long)d.N * d.H * d.W;
+    if (M <= 0 || M > 0x7fffffffLL) return 0;
+    p.M = (int)M;
+    const int ks = generic_ksplit(p);
+    return ks > 1 ? (size_t)ks * M * d.Cin * sizeof(float) : 0;
+}
+
 // dx[N,H,W,Cin] = conv_transpose(dz[N,Ho,Wo,Cout], w): the forward descriptor `d` describes the conv whose
 // input gradient is wanted; dz and dx are dense NHWC f32.
 int generic_dgrad_launch(const srmi_conv_desc& d, const ConvGeom& g, const float* dz, const float* w_dgrad, float* dx,
-                         hipStream_t s) {
+                         hipStream_t s, void* ws, size_t ws_bytes) {
     GenericParams p;
-    memset(&p, 0, sizeof(p));
+    generic_dgrad_fill(p, d, g);
     p.stream = s;
     p.x = dz; p.w = w_dgrad; p.y = dx;
+    p.vec_ok = d.Cout % 8 == 0 && ((uintptr_t)dz % 16) == 0;
+    p.partial = (float*)ws;
+    p.partial_stride = ws ? ws_bytes / sizeof(float) : 0;
+    const long long M = (long long)d.N * d.H * d.W;
+    if (M > 0x7fffffffLL) { set_error("dgrad: N*H*W = %lld exceeds int32", M); return SRMI_EINVAL; }
+    p.M = (int)M;
+    if (p.M == 0) return SRMI_OK;
+    return generic_run(p);
+}
+
+static void generic_dgrad_fill(GenericParams& p, const srmi_conv_desc& d, const ConvGeom& g) {
+    memset(&p, 0, sizeof(p));
     p.N = d.N; p.H = g.Ho; p.W = g.Wo; p.Cin = d.Cout; p.Cout = d.Cin; p.kh = d.kh; p.kw = d.kw;
     p.stride = d.stride; p.pad = d.pad;
     p.Ho = d.H; p.Wo = d.W; p.Cf = d.Cin; p.Hf = d.H; p.Wf = d.W;
     p.in_cs = d.Cout; p.out_cs = d.Cin; p.out_co = 0; p.res_cs = d.Cin;
-    p.vec_ok = d.Cout % 8 == 0 && ((uintptr_t)dz % 16) == 0;
     p.act = SRMI_ACT_NONE; p.r = 1;
     p.Cin_pad = round_up(d.Cout, 8); p.Cout_pad = round_up(d.Cin, 32);
-    const long long M = (long long)d.N * d.H * d.W;
-    if (M > 0x7fffffffLL) { set_error("dgrad: N*H*W = %lld exceeds int32", M); return SRMI_EINVAL; }
-    p.M = (int)M;
     p.transposed = 1;
-    if (p.M == 0) return SRMI_OK;
-    return generic_run(p);
+    p.ksplit = 1;
 }
 
 }  // namespace srmi

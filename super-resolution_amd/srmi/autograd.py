@@ -19,6 +19,7 @@ There is no fallback to ATen convolution / batch-norm kernels anywhere in this f
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import torch
 import torch.nn as nn
@@ -76,6 +77,56 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+class _Workspace:
+    """One growing device buffer per (device, stream) for the split-K slices of fwd / dgrad / wgrad.  Kernels that
+    use it are enqueued on that stream and consume it before the next one starts, so sharing is ordered."""
+
+    def __init__(self):
+        self.bufs = {}
+
+    def get(self, nbytes, device):
+        if nbytes == 0:
+            return None
+        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        t = self.bufs.get(key)
+        if t is None or t.numel() < nbytes:
+            t = self.bufs[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        return t
+
+
+_WS = _Workspace()
+
+
+class _PackCache:
+    """Packed forward / dgrad weights per parameter VERSION: re-packed only after the optimizer (or anything else
+    torch versions) has written the weight - once per step, not once per call (the discriminator and the frozen VGG run
+    several times per SRGAN iteration, P/mode.py:150-151, :165, :167).  Keyed by the parameter OBJECT (the base tensor of
+    a `.view()`, so nn.Linear's weight viewed as OIHW hits its entry) and held through a weak reference: an entry dies
+    with its parameter and can never be served to a new tensor that happens to reuse the address.  A write through
+    `.data` is invisible to the version counter: call srmi.invalidate(module), which clears this cache too."""
+
+    def __init__(self):
+        self.entries = {}
+
+    def get(self, kind, w, build):
+        base = w._base if w._base is not None else w
+        key = (kind, id(base), tuple(w.shape))
+        hit = self.entries.get(key)
+        if hit is not None and hit[0]() is base and hit[1] == (base._version, base.data_ptr()):
+            return hit[2]
+        packed = build()
+        if len(self.entries) > 4096:           # dead entries of discarded models
+            self.entries = {k: v for k, v in self.entries.items() if v[0]() is not None}
+        self.entries[key] = (weakref.ref(base), (base._version, base.data_ptr()), packed)
+        return packed
+
+    def clear(self):
+        self.entries.clear()
+
+
+_PACKS = _PackCache()
+
+
 class _Cfg:
     """static (non-tensor) configuration of one fused op"""
 
@@ -98,7 +149,7 @@ class FusedConvFn(torch.autograd.Function):
         desc = Fn.make_desc(N, H, W, Cin, Cout, (kh, kw), stride=cfg.stride, pad=cfg.pad, compute=L.COMPUTE_F32)
         _, _, Ho, Wo = Fn.out_shape(desc)
         w = weight.detach().contiguous()
-        wp = Fn.pack_weights(desc, w)
+        wp = _PACKS.get("fwd", weight, lambda: Fn.pack_weights(desc, w))
         shift = bias.detach().contiguous() if bias is not None else None
         z = _empty_cl((N, Cout, Ho, Wo), dev)
         # scale NULL = 1: lets the kernel split K on small maps; the workspace makes that split deterministic
@@ -106,7 +157,7 @@ class FusedConvFn(torch.autograd.Function):
         Fn.fill_args(a, desc, x, wp, None, shift, None, None, z)
         nws = C.c_size_t(0)
         L.check(lib.srmi_conv2d_workspace_bytes(C.byref(desc), C.byref(nws)))
-        wsk = torch.empty(nws.value, dtype=torch.uint8, device=dev) if nws.value else None
+        wsk = _WS.get(nws.value, dev)
         L.check(lib.srmi_conv2d_fwd_ws(C.byref(a), _ptr(wsk), nws.value, st))
 
         bn = cfg.bn
@@ -140,6 +191,7 @@ class FusedConvFn(torch.autograd.Function):
         ctx.save_for_backward(x, w, z, mean, rstd, g_, b_, a)
         ctx.cfg, ctx.desc, ctx.ed = cfg, desc, ed
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
+        ctx.weight_obj = weight        # cache key of the packed dgrad operand (an input: no reference cycle)
         return y
 
     @staticmethod
@@ -162,16 +214,26 @@ class FusedConvFn(torch.autograd.Function):
                                       _ptr(dalpha), ws.data_ptr(), st))
         need = ctx.needs_input_grad
         dx = dw = dbias = dgamma = dbeta = None
+        nws = C.c_size_t(0)
         if need[1]:
             dw = torch.empty_like(w)
-            L.check(lib.srmi_conv2d_wgrad(C.byref(desc), x.data_ptr(), dz.data_ptr(), dw.data_ptr(), st))
+            L.check(lib.srmi_conv2d_wgrad_workspace_bytes(C.byref(desc), C.byref(nws)))
+            wsk = _WS.get(nws.value, dev)
+            L.check(lib.srmi_conv2d_wgrad(C.byref(desc), x.data_ptr(), dz.data_ptr(), dw.data_ptr(), _ptr(wsk),
+                                          nws.value, st))
         if need[0]:
-            nbytes = C.c_size_t(0)
-            L.check(lib.srmi_conv2d_dgrad_packed_weight_bytes(C.byref(desc), C.byref(nbytes)))
-            wd = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
-            L.check(lib.srmi_conv2d_dgrad_pack_weights(C.byref(desc), w.data_ptr(), wd.data_ptr(), st))
+            def pack_dgrad():
+                nbytes = C.c_size_t(0)
+                L.check(lib.srmi_conv2d_dgrad_packed_weight_bytes(C.byref(desc), C.byref(nbytes)))
+                wd_ = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+                L.check(lib.srmi_conv2d_dgrad_pack_weights(C.byref(desc), w.data_ptr(), wd_.data_ptr(), st))
+                return wd_
+            wd = _PACKS.get("dgrad", ctx.weight_obj, pack_dgrad)
             dx = torch.empty_like(x)
-            L.check(lib.srmi_conv2d_dgrad(C.byref(desc), dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), st))
+            L.check(lib.srmi_conv2d_dgrad_workspace_bytes(C.byref(desc), C.byref(nws)))
+            wsk = _WS.get(nws.value, dev)
+            L.check(lib.srmi_conv2d_dgrad(C.byref(desc), dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), _ptr(wsk),
+                                          nws.value, st))
         if cfg.bn is not None:
             dgamma, dbeta = dsum2, dsum1
             # the bias of a conv feeding train-mode BN has an exactly-zero gradient (BN removes the mean)

@@ -34,6 +34,8 @@ def invalidate(module: nn.Module):
         if cache is not None and hasattr(cache, "entries"):
             cache.entries.clear()
             cache.sig = None
+    from . import autograd
+    autograd._PACKS.clear()
     return module
 
 

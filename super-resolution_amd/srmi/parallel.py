@@ -9,8 +9,15 @@ needs is the average of each model's gradients right before its optimizer step:
 
 Gradients are packed into a few large flat buckets (xGMI rings are per-link bound: fewer, larger
 collectives) and reduced with `torch.distributed.all_reduce` - RCCL on the "nccl" backend, gloo on CPU.
-Buckets are launched asynchronously in reverse parameter order so the first ones overlap the packing of
-the rest.  The frozen VGG has no gradients and takes no part.
+The frozen VGG has no gradients and takes no part.
+
+Two forms:
+  * `average_gradients(params)` after `backward()` - the two-line change to the reference loop shown above;
+  * `GradientAverager(params)` - persistent flat buckets filled by post-accumulate-grad hooks WHILE backward runs:
+    a bucket's all-reduce starts as soon as its last gradient has been produced (the discriminator's 75 MB Linear
+    gradient reduces while the conv layers' backward is still computing), `.grad` becomes a view of the bucket (no
+    copy back), and `finish()` before `optim.step()` only waits and scales.  One pass over the gradients instead of
+    three, overlapped with backward.
 """
 from __future__ import annotations
 
@@ -42,6 +49,17 @@ def _buckets(params, max_buckets):
     return out
 
 
+def _all_reduce(flat, group, async_op):
+    """SUM all-reduce of a flat bucket.  gloo cannot be relied on for device tensors in every build: a device bucket
+    under gloo (debug / single-GPU rehearsal runs) is staged through the host."""
+    if flat.is_cuda and dist.get_backend(group) == "gloo":
+        host = flat.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+        flat.copy_(host)
+        return None
+    return dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=async_op)
+
+
 def average_gradients(params, group=None, max_buckets=4):
     """In-place mean of `.grad` over the ranks of `group`.  No-op when torch.distributed is not initialised or
     the world has one rank.  Returns the number of buckets reduced."""
@@ -54,11 +72,12 @@ def average_gradients(params, group=None, max_buckets=4):
     work = []
     for b in buckets:
         flat = torch.cat([p.grad.reshape(-1) for p in b])
-        h = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group, async_op=True)
+        h = _all_reduce(flat, group, True)
         work.append((b, flat, h))
     inv = 1.0 / world
     for b, flat, h in work:
-        h.wait()
+        if h is not None:
+            h.wait()
         off = 0
         for p in b:
             n = p.grad.numel()
@@ -71,9 +90,100 @@ def broadcast_parameters(module, src=0, group=None):
     """Make every rank start from rank `src`'s parameters and buffers (call once before training)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return
+    host_staged = dist.get_backend(group) == "gloo"
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
             # .detach() shares the version counter with t (t.data would not): cached inference plans see the write
-            dist.broadcast(t.detach(), src=src, group=group)
+            if host_staged and t.is_cuda:            # gloo + device tensors: through the host (see _all_reduce)
+                h = t.detach().cpu()
+                dist.broadcast(h, src=src, group=group)
+                t.detach().copy_(h)
+            else:
+                dist.broadcast(t.detach(), src=src, group=group)
     from .engine import invalidate
     invalidate(module)      # belt and braces: a collective backend that writes below torch's version tracking
+
+
+class GradientAverager:
+    """Overlapped form of `average_gradients` for one model (see the module docstring).
+
+        avg = GradientAverager(discriminator.parameters())
+        ...
+        d_loss.backward()          # hooks fill the buckets and launch their all-reduces as backward proceeds
+        avg.finish()               # wait + scale by 1/world; p.grad is now a view of its bucket
+        d_optim.step()
+
+    Works with the reference loop's `zero_grad()` (grads set to None): each backward hands the hook a fresh gradient,
+    which is copied into the bucket once.  With world size 1 (or no process group) it does nothing."""
+
+    def __init__(self, params, group=None, max_buckets=4):
+        self.group = group
+        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.params = []
+        seen = set()
+        for p in params:
+            if p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                self.params.append(p)
+        self.buckets = []          # [flat tensor, [(param, offset, numel)], pending count, work handle]
+        self.where = {}
+        self.handles = []
+        if not self.active or not self.params:
+            return
+        self.inv = 1.0 / dist.get_world_size(group)
+        total = sum(p.numel() for p in self.params)
+        target = max(1, -(-total // max(1, max_buckets)))
+        cur, n = [], 0
+        groups = []
+        for p in reversed(self.params):               # backward produces the last layers' gradients first
+            cur.append(p)
+            n += p.numel()
+            if n >= target:
+                groups.append(cur)
+                cur, n = [], 0
+        if cur:
+            groups.append(cur)
+        for gi, ps in enumerate(groups):
+            flat = torch.zeros(sum(p.numel() for p in ps), dtype=ps[0].dtype, device=ps[0].device)
+            slots, off = [], 0
+            for p in ps:
+                slots.append((p, off, p.numel()))
+                self.where[id(p)] = (gi, off)
+                off += p.numel()
+            self.buckets.append([flat, slots, len(slots), None])
+        for p in self.params:
+            self.handles.append(p.register_post_accumulate_grad_hook(self._hook))
+
+    def _hook(self, p):
+        gi, off = self.where[id(p)]
+        b = self.buckets[gi]
+        view = b[0][off:off + p.numel()].view_as(p)
+        if p.grad.data_ptr() != view.data_ptr():
+            view.copy_(p.grad)
+            p.grad = view
+        b[2] -= 1
+        if b[2] == 0:
+            b[3] = _all_reduce(b[0], self.group, True)
+
+    def finish(self):
+        """Wait for every bucket, scale to the mean.  Buckets whose parameters received no gradient this backward
+        (unused parameters) are skipped on every rank alike.  Returns the number of buckets reduced."""
+        if not self.active:
+            return 0
+        done = 0
+        for b in self.buckets:
+            if b[2] == 0:
+                if b[3] is not None:
+                    b[3].wait()
+                b[0].mul_(self.inv)
+                done += 1
+            elif b[2] != len(b[1]):
+                raise RuntimeError("GradientAverager: a bucket received gradients for only some of its parameters; "
+                                   "use average_gradients() for models with conditionally unused parameters")
+            b[2], b[3] = len(b[1]), None
+        return done
+
+    def close(self):
+        for h in self.handles:
+            h.remove()
+        self.handles = []

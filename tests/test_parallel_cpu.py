@@ -22,7 +22,7 @@ def _data():
     return torch.randn(4, 3, 6, 6, generator=g), torch.randn(4, 3, 6, 6, generator=g)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, overlapped=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -36,11 +36,23 @@ def _worker(rank, world, port, q):
         x, y = _data()
         xs, ys = x[rank * 2:(rank + 1) * 2], y[rank * 2:(rank + 1) * 2]
         opt = torch.optim.Adam(m.parameters(), lr=1e-3)
-        loss = nn.functional.mse_loss(m(xs), ys)
-        opt.zero_grad()
-        loss.backward()
-        local = [p.grad.clone() for p in m.parameters()]
-        nb = parallel.average_gradients(m.parameters(), max_buckets=2)
+        if overlapped:
+            # local gradients first (no exchange), then the same backward with the hooks in place
+            nn.functional.mse_loss(m(xs), ys).backward()
+            local = [p.grad.clone() for p in m.parameters()]
+            avg = parallel.GradientAverager(m.parameters(), max_buckets=2)
+            opt.zero_grad()                               # grads -> None, as the reference loop leaves them
+            nn.functional.mse_loss(m(xs), ys).backward()
+            nb = avg.finish()
+            assert all(p.grad.data_ptr() == avg.buckets[avg.where[id(p)][0]][0].data_ptr() + 4 * avg.where[id(p)][1]
+                       for p in m.parameters())           # .grad is a view of its bucket: no copy back
+            avg.close()
+        else:
+            loss = nn.functional.mse_loss(m(xs), ys)
+            opt.zero_grad()
+            loss.backward()
+            local = [p.grad.clone() for p in m.parameters()]
+            nb = parallel.average_gradients(m.parameters(), max_buckets=2)
         opt.step()
         q.put((rank, nb, [t.numpy() for t in local], [p.grad.numpy().copy() for p in m.parameters()],
                [p.detach().numpy().copy() for p in m.parameters()]))
@@ -48,11 +60,15 @@ def _worker(rank, world, port, q):
         dist.destroy_process_group()
 
 
-def test_two_rank_gradient_average_matches_single_process_oracle():
+import pytest
+
+
+@pytest.mark.parametrize("overlapped", [False, True])
+def test_two_rank_gradient_average_matches_single_process_oracle(overlapped):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + os.getpid() % 2000
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    port = 31500 + os.getpid() % 2000 + int(overlapped)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, overlapped)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted((q.get(timeout=120) for _ in procs), key=lambda r: r[0])

@@ -4,13 +4,13 @@ fixtures produced by the REFERENCE modules on CPU (oracle/make_golden.py::srgan_
 are the seeded recipe of oracle/weights.py because ImageNet weights are unavailable offline - the perceptual
 term is therefore pinned to the reference's arithmetic, not to real VGG features).
 
-Tolerances.  Losses and BN statistics are compared tightly.  Gradients that have crossed several
-LeakyReLU/PReLU/ReLU layers are compared in relative L2 (<= 5 % for D, <= 10 % for G after D's Adam step) with a 20 %-of-max cap per element: with ~5e6 pre-activations
-per pass a handful lie within fp32 rounding of the kink (measured: 2 of 4.9e6 differ in sign between this
-kernel's and oneDNN's summation order, |u| < 4e-6), each flips one derivative between slope and 1 and
-perturbs every upstream gradient by ~1e-2 of its max.  The reference's own fp32 run has the same sensitivity
-(it moves by the same amount when its summation order changes); per-op gradients are pinned to 2e-4 in
-tests/test_train_ops_gpu.py and the kink-free pre-training step in tests/test_train_step_gpu.py."""
+Tolerances.  The training kernels are deterministic (no float atomics: split-K slices of fwd / dgrad / wgrad are stored
+and added in a fixed order), so every number here is reproducible to the bit and the gates are set from measurements
+(STEP_CASES below).  Losses and BN statistics are compared tightly.  Gradients are gated three ways: per tensor
+against the reference's fp32 gradients (max-abs and relative L2, ~2.5x the measured distance); against a float64 run
+of the same iteration stored in the fixture (srmi must be about as close to it as the reference's own fp32 run is);
+and bit-equality of two runs.  What limits the first gate is fp32 itself: a handful of ~1e7 pre-activations lie within
+rounding of a (Leaky)ReLU kink, and Adam's first step is lr * sign(grad) (see STEP_CASES)."""
 import os
 
 import numpy as np
@@ -39,7 +39,34 @@ def _bn_fed_bias(name, keys):
     return name.endswith("body.0.bias") and name[:-len("0.bias")] + "1.running_mean" in keys
 
 
-def _cmp(g, prefix, name, got, tol_rel, tol_abs=1e-7, keys=(), deep=False):
+def _fixture_tensor(g, prefix, name, like=None):
+    """The fixture's tensor (or its strided sample) and, when `like` is given, the matching view of `like`."""
+    if f"{prefix}:{name}" in g.files:
+        ref = torch.from_numpy(g[f"{prefix}:{name}"]).reshape(-1)
+        return ref, (like.detach().float().cpu().reshape(-1) if like is not None else None)
+    if f"{prefix}_sample:{name}" in g.files:
+        stride = int(g[f"{prefix}_stride:{name}"])
+        ref = torch.from_numpy(g[f"{prefix}_sample:{name}"])
+        return ref, (like.detach().float().cpu().reshape(-1)[::stride] if like is not None else None)
+    return None, None
+
+
+def grad_errors(g, prefix, name, got, truth=None):
+    """(relative L2 error, max error / max|ref|) of one gradient tensor against the fixture entry `truth or prefix`
+    (full tensor, or the strided sample the fixture keeps for large tensors); None when the fixture does not hold it.
+    got = None compares the fixture's own `prefix` entry (the reference's fp32 result) with `truth`."""
+    ref, mine = _fixture_tensor(g, truth or prefix, name, got)
+    if ref is None:
+        return None
+    if got is None:
+        mine, _ = _fixture_tensor(g, prefix, name)
+    diff = mine.double() - ref.double()
+    rn, rmax = float(ref.double().norm()), float(ref.abs().max()) if ref.numel() else 0.0
+    return float(diff.norm()) / max(rn, 1e-30), float(diff.abs().max()) / max(rmax, 1e-30)
+
+
+def _cmp(g, prefix, name, got, tol_rel, tol_abs=1e-7, keys=(), l2=None):
+    """max-abs error <= tol_rel * max|ref| (+ tol_abs); with l2 set, also relative L2 error <= l2."""
     got = got.detach().float().cpu()
     if _bn_fed_bias(name, keys):
         assert float(got.abs().max()) == 0.0
@@ -48,28 +75,25 @@ def _cmp(g, prefix, name, got, tol_rel, tol_abs=1e-7, keys=(), deep=False):
     if f"{prefix}:{name}" in g.files:
         ref = torch.from_numpy(g[f"{prefix}:{name}"])
         scale = float(ref.abs().max()) if ref.numel() else 0.0
-        if deep:
-            assert float((got - ref).abs().max()) <= 0.2 * scale + tol_abs, (prefix, name)
-            assert float((got - ref).norm()) <= tol_rel * float(ref.norm()) + tol_abs, (prefix, name, "L2")
-        else:
-            assert float((got - ref).abs().max()) <= tol_rel * scale + tol_abs, (prefix, name)
+        assert float((got - ref).abs().max()) <= tol_rel * scale + tol_abs, (prefix, name)
+        if l2 is not None:
+            assert float((got - ref).norm()) <= l2 * float(ref.norm()) + tol_abs, (prefix, name, "L2")
         return
     stride = int(g[f"{prefix}_stride:{name}"])
     absmax = float(g[f"{prefix}_absmax:{name}"])
     flat = got.reshape(-1)
     ref_s = torch.from_numpy(g[f"{prefix}_sample:{name}"])
-    if deep:
-        assert float((flat[::stride] - ref_s).abs().max()) <= 0.2 * absmax + tol_abs, (prefix, name)
-        assert float((flat[::stride] - ref_s).norm()) <= tol_rel * float(ref_s.norm()) + tol_abs, (prefix, name, "L2")
-    else:
-        assert float((flat[::stride] - ref_s).abs().max()) <= tol_rel * absmax + tol_abs, (prefix, name)
+    assert float((flat[::stride] - ref_s).abs().max()) <= tol_rel * absmax + tol_abs, (prefix, name)
+    if l2 is not None:
+        assert float((flat[::stride] - ref_s).norm()) <= l2 * float(ref_s.norm()) + tol_abs, (prefix, name, "L2")
     sumsq = float(g[f"{prefix}_sumsq:{name}"])
-    assert abs(float((flat.double() ** 2).sum()) - sumsq) <= max(5 * tol_rel, 0.02) * sumsq + 1e-12, (prefix, name, "sumsq")
+    assert abs(float((flat.double() ** 2).sum()) - sumsq) <= max(5 * tol_rel, 2 * (l2 or 0.0), 1e-3) * sumsq + 1e-12, \
+        (prefix, name, "sumsq")
 
 
-@pytest.mark.parametrize("fname", ["srgan_step_b8_lr16_tv0.npz", "srgan_step_b8_lr16_tv.npz"])
-def test_srgan_finetune_step(golden_dir, fname):
-    g = np.load(os.path.join(golden_dir, fname), allow_pickle=False)
+def run_step(g):
+    """One fine-tune iteration, P/mode.py:148-179, written as the reference writes it, on srmi modules with the fixture's
+    recipe weights and inputs.  Returns losses, D grads (before d_optim.step), G grads, and the modules."""
     num_block, batch, lr_hw, tv_coeff = int(g["num_block"]), int(g["batch"]), int(g["lr_hw"]), float(g["tv_coeff"])
     wseed, xseed = int(g["wseed"]), int(g["xseed"])
     patch = lr_hw * 4
@@ -80,7 +104,6 @@ def test_srgan_finetune_step(golden_dir, fname):
     gt = torch.from_numpy(W.lr_input((batch, 3, patch, patch), seed=xseed + 1)).to(DEV)
     vgg_rescale_coeff, adv_coeff, feat_layer = 0.006, 1e-3, "relu5_4"
 
-    gkeys, dkeys = set(generator.state_dict().keys()), set(discriminator.state_dict().keys())
     l2_loss = losses.MSELoss()
     g_optim = optim.Adam(generator.parameters(), lr=1e-4)
     d_optim = optim.Adam(discriminator.parameters(), lr=1e-4)
@@ -100,9 +123,7 @@ def test_srgan_finetune_step(golden_dir, fname):
     g_optim.zero_grad()
     d_optim.zero_grad()
     d_loss.backward()
-    assert abs(d_loss.item() - float(g["d_loss"])) <= 5e-6
-    for name, p in discriminator.named_parameters():
-        _cmp(g, "dgrad", name, p.grad, 5e-2, keys=dkeys, deep=True)
+    res = dict(d_loss=d_loss.item(), dgrad={n: p.grad.detach().clone() for n, p in discriminator.named_parameters()})
     d_optim.step()
 
     # Training Generator (P/mode.py:163-179)
@@ -117,21 +138,63 @@ def test_srgan_finetune_step(golden_dir, fname):
     g_optim.zero_grad()
     d_optim.zero_grad()
     g_loss.backward()
+    res.update(ggrad={n: p.grad.detach().clone() for n, p in generator.named_parameters()})
     g_optim.step()
+    res.update(g_loss=g_loss.item(), percep_loss=percep_loss.item(), adversarial_loss=adversarial_loss.item(),
+               total_variance_loss=total_variance_loss.item(), L2_loss=L2_loss.item(),
+               hr_feat_absmax=float(hr_feat.abs().max()), generator=generator, discriminator=discriminator)
+    return res
 
-    assert abs(percep_loss.item() - float(g["percep_loss"])) <= 2e-4 * float(g["percep_loss"])
-    assert abs(adversarial_loss.item() - float(g["adversarial_loss"])) <= 1e-3 * float(g["adversarial_loss"])
-    assert abs(total_variance_loss.item() - float(g["total_variance_loss"])) <= 1e-3 * abs(float(g["total_variance_loss"])) + 1e-12
-    assert abs(L2_loss.item() - float(g["L2_loss"])) <= 2e-6
-    assert abs(g_loss.item() - float(g["g_loss"])) <= 5e-6
-    assert abs(float(hr_feat.abs().max()) - float(g["hr_feat_absmax"])) <= 1e-4 * float(g["hr_feat_absmax"])
-    for name, p in generator.named_parameters():
-        # 6 %: on top of the kink flips, the discriminator was just moved by Adam's FIRST step, which is
-        # lr*sign(grad) for every element - elements whose (noise-level) gradient differs in sign from the
-        # reference's land 2e-4 apart, which perturbs the adversarial gradient (38 % of conv01's total) by a
-        # few percent.  The three loss terms are pinned separately, with an un-stepped D, in
-        # test_generator_loss_terms_vs_oracle below (<= 5e-4 / 5e-3).
-        _cmp(g, "ggrad", name, p.grad, 1e-1, keys=gkeys, deep=True)
+
+# (fixture, (max-abs gate as a fraction of max|ref|, relative-L2 gate) for the D grads, the same for the G grads), all
+# against the REFERENCE's fp32 gradients.  The training kernels are deterministic (no float atomics), so these are
+# fixed numbers: MEASURED on MI355X by tools/measure_step_error.py (gpurun_out/r2c), gates at
+# ~2.5x the measurement:
+#   b8_lr16_tv0   D 8.5e-6 max / 8.5e-6 L2     G 4.5e-4 / 3.9e-4
+#   b8_lr16_tv    D 1.1e-2 / 2.4e-3            G 3.2e-2 / 2.8e-2   <- the REFERENCE's fp32 run sits 2.4e-3 / 2.8e-2 from the
+#                                                 float64 run of the same graph here (ours: 8.8e-6 / 1.8e-4): a pre-activation
+#                                                 of ITS forward fell on the other side of a LeakyReLU kink
+#   default cfg3  D 1.4e-2 / 5.1e-3            G 5.8e-2 / 5.0e-2   (reference vs float64: 3.1e-3 / 4.1e-2; ours 6.0e-3 / 5.5e-2)
+# What bounds them is not kernel arithmetic but fp32 itself: of ~1e7 pre-activations a handful lie within rounding of a
+# (Leaky)ReLU kink, and Adam's FIRST step is lr * sign(grad), which turns noise-level gradient signs of D into 2e-4
+# parameter differences before the G step.  The yardstick test below makes that precise: against a float64 run of the
+# same iteration (fixture entries dgrad64 / ggrad64) srmi's fp32 gradients must be about as close as the reference's.
+STEP_CASES = [
+    ("srgan_step_b8_lr16_tv0.npz", (3e-5, 3e-5), (1.2e-3, 1e-3)),
+    ("srgan_step_b8_lr16_tv.npz", (3e-2, 6e-3), (8e-2, 6e-2)),
+    ("srgan_step_default_b16_lr24.npz", (3.5e-2, 1.3e-2), (1.5e-1, 1.2e-1)),   # the reference's default configuration = BASELINE cfg3 per GPU
+]
+YARDSTICK_RATIO, YARDSTICK_FLOOR = 3.0, 5e-5
+
+
+@pytest.mark.parametrize("fname,dtol,gtol", STEP_CASES)
+def test_srgan_finetune_step(golden_dir, fname, dtol, gtol):
+    g = np.load(os.path.join(golden_dir, fname), allow_pickle=False)
+    r = run_step(g)
+    generator, discriminator = r["generator"], r["discriminator"]
+    gkeys, dkeys = set(generator.state_dict().keys()), set(discriminator.state_dict().keys())
+    assert abs(r["d_loss"] - float(g["d_loss"])) <= 5e-6
+    for name, grad in r["dgrad"].items():
+        _cmp(g, "dgrad", name, grad, dtol[0], keys=dkeys, l2=dtol[1])
+    assert abs(r["percep_loss"] - float(g["percep_loss"])) <= 2e-4 * float(g["percep_loss"])
+    assert abs(r["adversarial_loss"] - float(g["adversarial_loss"])) <= 1e-3 * float(g["adversarial_loss"])
+    assert abs(r["total_variance_loss"] - float(g["total_variance_loss"])) <= 1e-3 * abs(float(g["total_variance_loss"])) + 1e-12
+    assert abs(r["L2_loss"] - float(g["L2_loss"])) <= 2e-6
+    assert abs(r["g_loss"] - float(g["g_loss"])) <= 5e-6
+    assert abs(r["hr_feat_absmax"] - float(g["hr_feat_absmax"])) <= 1e-4 * float(g["hr_feat_absmax"])
+    for name, grad in r["ggrad"].items():
+        _cmp(g, "ggrad", name, grad, gtol[0], keys=gkeys, l2=gtol[1])
+    # float64 yardstick: worst and median relative-L2 distance to the f64 run, ours vs the reference's own fp32
+    for prefix, keys in (("dgrad", dkeys), ("ggrad", gkeys)):
+        ours, refs = [], []
+        for name, grad in r[prefix].items():
+            if _bn_fed_bias(name, keys):
+                continue
+            ours.append(grad_errors(g, prefix, name, grad, truth=prefix + "64")[0])
+            refs.append(grad_errors(g, prefix, name, None, truth=prefix + "64")[0])
+        med = lambda v: sorted(v)[len(v) // 2]
+        assert max(ours) <= max(YARDSTICK_RATIO * max(refs), YARDSTICK_FLOOR), (prefix, "max", max(ours), max(refs))
+        assert med(ours) <= max(YARDSTICK_RATIO * med(refs), YARDSTICK_FLOOR), (prefix, "median", med(ours), med(refs))
     # post-step state: BN buffers tightly (3 train-mode forwards of D, 2 of G); parameters within Adam's reach
     for name, v in generator.state_dict().items():
         if "running" in name:
@@ -145,14 +208,21 @@ def test_srgan_finetune_step(golden_dir, fname):
             assert int(v) == int(g["after_d:" + name]) == 3
 
 
-@pytest.mark.parametrize("term,tol", [("l2", 2e-3), ("adv", 1e-2), ("percep", 2e-2)])
-def test_generator_loss_terms_vs_oracle(term, tol):
-    """Each term of g_loss (P/mode.py:167-174) on its own, gradients w.r.t. every Generator parameter, against
-    the oracle run in fp32 on the host (measured: both sit at the same distance from an fp64 run - 1e-6 for
-    L2, 5e-5 for the adversarial term, 2e-3 for the perceptual term whose 16 ReLU layers have kinks).  The bounds
-    leave room for ONE activation-kink flip (a pre-activation within 1e-6 of zero landing on the other side:
-    seen in about one run in three, because the split-K convolutions add their partial sums with f32 atomics
-    in a run-dependent order), which moves a whole gradient tensor by up to 4e-3 in relative L2."""
+def test_srgan_step_is_bit_reproducible(golden_dir):
+    """No floating-point atomics anywhere in the training path (split-K slices of fwd / dgrad / wgrad are stored and
+    added in a fixed order): two runs of the full D step + G step from the same state give the same bits for every
+    gradient and both losses."""
+    g = np.load(os.path.join(golden_dir, "srgan_step_b8_lr16_tv.npz"), allow_pickle=False)
+    a, b = run_step(g), run_step(g)
+    assert a["d_loss"] == b["d_loss"] and a["g_loss"] == b["g_loss"]
+    for prefix in ("dgrad", "ggrad"):
+        for name in a[prefix]:
+            assert torch.equal(a[prefix][name], b[prefix][name]), (prefix, name)
+
+
+def loss_term_errors(term):
+    """One term of g_loss (P/mode.py:167-174) on its own: (relative loss error, worst relative-L2 gradient error over the
+    Generator's parameters) against the oracle run in fp32 on the host."""
     B, L, xseed = 8, 16, 41
     g_np = W.generator_weights(seed=0, num_block=2)
     d_np = W.discriminator_weights(seed=1, patch_size=4 * L)
@@ -192,14 +262,25 @@ def test_generator_loss_terms_vs_oracle(term, tol):
         loss = 0.006 * losses.perceptual_loss(V)((gtd + 1) / 2, (outd + 1) / 2)[0]
     G.zero_grad()       # the default-argument PReLU is ONE parameter shared by every Generator of the process (P/srgan_model.py:8)
     loss.backward()
-    assert abs(loss.item() - ref_loss.item()) <= 1e-5 * abs(ref_loss.item()) + 1e-9
     keys = set(G.state_dict().keys())
+    worst = 0.0
     for name, prm in G.named_parameters():
         if _bn_fed_bias(name, keys):
             continue
         ref = gsd[name].grad
-        err = float((prm.grad.cpu() - ref).norm()) / float(ref.norm())
-        assert err <= tol, (term, name, err)
+        worst = max(worst, float((prm.grad.cpu() - ref).norm()) / float(ref.norm()))
+    return abs(loss.item() - ref_loss.item()) / max(abs(ref_loss.item()), 1e-30), worst
+
+
+# measured on MI355X with the deterministic kernels (tools/measure_step_error.py): l2 1.1e-6, adv 9.7e-5, percep 3.1e-3
+@pytest.mark.parametrize("term,tol", [("l2", 5e-6), ("adv", 3e-4), ("percep", 8e-3)])
+def test_generator_loss_terms_vs_oracle(term, tol):
+    """Each term of g_loss (P/mode.py:167-174) on its own, gradients w.r.t. every Generator parameter, against
+    the oracle run in fp32 on the host (both sit at the same distance from an fp64 run - 1e-6 for L2, 5e-5 for the
+    adversarial term, 2e-3 for the perceptual term whose 16 ReLU layers have kinks)."""
+    loss_err, grad_err = loss_term_errors(term)
+    assert loss_err <= 1e-5
+    assert grad_err <= tol, (term, grad_err)
 
 
 def test_perceptual_loss_gradient_vs_oracle():
