@@ -228,6 +228,17 @@ int srmi_crop_augment_u8(const uint8_t* lr_pack, const uint8_t* gt_pack, const s
 /* out[0] = mean((a-b)^2) over n f32 elements.  Replaces nn.MSELoss (P/mode.py:89, :169; P/losses.py:30). */
 int srmi_mse_loss(const float* a, const float* b, size_t n, float* out, void* ws, void* stream);
 
+/* srmi_mse_loss for callers that can neither allocate nor hand over a workspace (code under HIP graph capture, tight
+ * serving loops, harnesses that forbid hipMalloc).  NO counterpart in the reference.  The f64 partials live in a
+ * SRMI_REDUCE_WS_BYTES (16 KiB) file-scope device array of the library (one copy per GPU, held until the process
+ * ends; its address is resolved once per device on the first call there).  The call enqueues two kernels on `stream`
+ * and calls no hipMalloc / hipFree / allocating routine.  n > SRMI_NOALLOC_MAX_ELEMS is rejected with SRMI_EINVAL.
+ * Every call on a GPU shares that GPU's array: calls that overlap in time on one GPU (two streams, two threads) RACE
+ * on it - serialise them on one stream, or use srmi_mse_loss with a workspace per stream.  The array needs no clearing
+ * between calls (every slot read was written by the same call).  Result bit-identical to srmi_mse_loss. */
+#define SRMI_NOALLOC_MAX_ELEMS ((size_t)1 << 32)
+int srmi_mse_loss_noalloc(const float* a, const float* b, size_t n, float* out, void* stream);
+
 /* out[0] = mean(-(t*log(p) + (1-t)*log(1-p))), logs clamped at -100.  Replaces nn.BCELoss on the
  * discriminator probabilities (P/mode.py:136, :153-154, :171). */
 int srmi_bce_loss(const float* p, const float* t, size_t n, float* out, void* ws, void* stream);

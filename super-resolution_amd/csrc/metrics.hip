@@ -4,6 +4,8 @@
 // workgroup in the caller's workspace (fixed grid, fixed grid-stride order, wave shuffle tree,
 // LDS across the four waves), stage 2 is one workgroup that adds the partials in index order
 // and writes the scalar(s).  No atomics, no host synchronisation, nothing allocated.
+#include <mutex>
+
 #include "common.h"
 
 namespace srmi {
@@ -271,3 +273,51 @@ int y_metrics(const float* sr, const float* gt, int nimg, int H, int W, int gt_H
 }
 
 }  // namespace srmi
+
+// ---- the one entry point that allocates nothing and takes no workspace (include/srmi.h) -----------------------------
+// srmi_mse_loss_noalloc = srmi_mse_loss with the per-workgroup f64 partials kept in a file-scope device array instead of
+// a caller workspace.  `srmi_noalloc_scratch` below is the HOST-SIDE STAND-IN of that array: its device address is
+// resolved once per device with hipGetSymbolAddress (each GPU holds its own copy at its own address) and only that
+// pointer is ever handed to a kernel.
+static __device__ __align__(256) unsigned char srmi_noalloc_scratch[SRMI_REDUCE_WS_BYTES];
+
+namespace srmi {
+constexpr int NOALLOC_MAX_DEVICES = 64;
+static void* g_noalloc_ptr[NOALLOC_MAX_DEVICES];   // per device; written once under the mutex, then read-only
+static std::mutex g_noalloc_mutex;
+
+// device pointer of this device's copy of the scratch array (resolved on the first call on each device)
+static int noalloc_scratch(void** out) {
+    int dev = -1;
+    int rc = hip_check(hipGetDevice(&dev), "hipGetDevice");
+    if (rc) return rc;
+    if (dev < 0 || dev >= NOALLOC_MAX_DEVICES) {
+        set_error("mse_loss_noalloc: device ordinal %d outside 0..%d", dev, NOALLOC_MAX_DEVICES - 1);
+        return SRMI_EUNSUPPORTED;
+    }
+    std::lock_guard<std::mutex> lock(g_noalloc_mutex);
+    if (!g_noalloc_ptr[dev]) {
+        void* p = nullptr;
+        rc = hip_check(hipGetSymbolAddress(&p, HIP_SYMBOL(srmi_noalloc_scratch)), "hipGetSymbolAddress(scratch)");
+        if (rc) return rc;
+        if (!p) { set_error("mse_loss_noalloc: hipGetSymbolAddress returned NULL"); return SRMI_EHIP; }
+        g_noalloc_ptr[dev] = p;
+    }
+    *out = g_noalloc_ptr[dev];
+    return SRMI_OK;
+}
+}  // namespace srmi
+
+extern "C" int srmi_mse_loss_noalloc(const float* a, const float* b, size_t n, float* out, void* stream) {
+    using namespace srmi;
+    if (!a || !b || !out) { set_error("mse_loss_noalloc: NULL argument"); return SRMI_EINVAL; }
+    if (n > (size_t)SRMI_NOALLOC_MAX_ELEMS) {
+        set_error("mse_loss_noalloc: n = %zu exceeds SRMI_NOALLOC_MAX_ELEMS = %zu", n, (size_t)SRMI_NOALLOC_MAX_ELEMS);
+        return SRMI_EINVAL;
+    }
+    void* ws = nullptr;
+    int rc = noalloc_scratch(&ws);
+    if (rc) return rc;
+    // nothing to clear: stage 1 overwrites slots 0..nb-1 and stage 2 reads exactly those slots
+    return pair_loss(OP_SQDIFF, a, b, n, out, ws, (hipStream_t)stream);
+}

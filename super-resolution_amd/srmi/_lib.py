@@ -104,6 +104,7 @@ SYMBOLS = {
     "srmi_f32nchw_to_u8hwc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                         C.c_void_p]),
     "srmi_mse_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "srmi_mse_loss_noalloc": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "srmi_bce_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "srmi_tv_loss": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p,
                                C.c_void_p, C.c_void_p]),
@@ -136,6 +137,7 @@ SYMBOLS = {
 }
 REDUCE_WS_BYTES = 16384
 METRICS_MAX_BATCH = 256
+NOALLOC_MAX_ELEMS = 1 << 32
 
 _LIB = None
 
