@@ -108,7 +108,90 @@ def per_kernel_times(gen, x, reps):
     return plan, units, tot / reps   # ms per launch
 
 
-def cpu_baseline(threads, sd, x):
+def host_cpu_info():
+    """CPU model, physical and logical core counts of the host, and the CPUs this process may run on."""
+    model, phys, logical = "unknown", set(), 0
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            k, _, v = line.partition(":")
+            k, v = k.strip(), v.strip()
+            if k == "model name":
+                model = v
+            elif k == "processor":
+                logical += 1
+            elif k == "physical id":
+                pid = v
+            elif k == "core id":
+                cid = v
+            elif not k and pid is not None:
+                phys.add((pid, cid)); pid = cid = None
+    except OSError:
+        pass
+    try:
+        allowed = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        allowed = os.cpu_count() or 1
+    return {"model": model, "physical_cores": len(phys) or None, "logical_cpus": logical or os.cpu_count(),
+            "cpus_allowed": allowed}
+
+
+def baseline_threads(info):
+    """Threads for the CPU leg: the job's CPU share.  OMP_NUM_THREADS is what the box allots a one-GPU job (16 of a
+    many-socket host); without it, the CPUs this process may run on, at most the physical core count."""
+    env = os.environ.get("OMP_NUM_THREADS", "")
+    if env.isdigit() and int(env) > 0:
+        return int(env)
+    n = info["cpus_allowed"]
+    if info["physical_cores"]:
+        n = min(n, info["physical_cores"])
+    return max(1, n)
+
+
+def hbm_bound_layers(plan, units, kms, gen, x):
+    """Achieved HBM GB/s of the memory-bound launches of the step (algorithmic bytes = compulsory input + output, SURVEY
+    8d3): last_conv 64->3 + tanh (128 B bf16 in + 12 B f32 out per output pixel) and the NHWC bf16 -> NCHW f32 re-layout
+    of `feat` (2 + 4 B per element), the latter timed here with its own pair of HIP events."""
+    from srmi import _lib as L
+    from srmi import functional as Fn
+    out = {}
+    for u, (label, i, cnt) in enumerate(units):
+        d = plan.args[i].d
+        if label == "c64_thin_bf16":
+            nbytes = d.N * d.H * d.W * (d.Cin * 2 + d.Cout * 4)
+            out[f"{label}:{d.Cin}->{d.Cout}@{d.H}x{d.W}"] = (nbytes, kms[u] * 1e-3)
+    reps = 10
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        Fn.layout_convert(plan.feat_nhwc, plan.N, plan.nf, plan.H, plan.W, L.NHWC, L.NCHW, torch.float32)
+    e1.record()
+    torch.cuda.synchronize()
+    out[f"feat_relayout:nhwc_bf16->nchw_f32@{plan.H}x{plan.W}x{plan.nf}"] = (
+        plan.N * plan.H * plan.W * plan.nf * 6, e0.elapsed_time(e1) * 1e-3 / reps)
+    return {k: {"algorithmic_bytes": b, "us": round(t * 1e6, 2), "GB/s": round(b / t / 1e9, 1),
+                "frac_of_8TB/s": round(b / t / 8e12, 4)} for k, (b, t) in out.items()}
+
+
+def fp32_path(dev, steps=3):
+    """The exact-f32 path (SRMI_COMPUTE_F32: the <=1e-4 parity path) on the same workload: MP/s and its fraction of the
+    157 TFLOP/s f32-MFMA peak."""
+    gen, x, _, _ = build_generator(dev, "fp32")
+    with torch.no_grad():
+        gen(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            gen(x)
+        torch.cuda.synchronize()
+        t = (time.perf_counter() - t0) / steps
+    mp = BATCH * (4 * LR_H) * (4 * LR_W) / 1e6
+    tf = mp * 1e6 * FLOP_PER_OUT_PIXEL / t / 1e12
+    return {"value": round(mp / t, 2), "unit": "MP/s", "ms_per_step": round(t * 1e3, 3), "dtype": "f32",
+            "tflops": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "steps": steps}
+
+
+def cpu_baseline(threads, sd, x, info=None):
     """The oracle (oracle/srgan_oracle.py: plain torch.nn.functional restatement, pinned bit-exact to the
     imported reference in the build container) on the host cores, same weights and inputs as the GPU leg."""
     from oracle import srgan_oracle as O
@@ -122,9 +205,12 @@ def cpu_baseline(threads, sd, x):
             times.append(time.perf_counter() - t0)
     t = float(np.median(times))
     mp = BATCH * (4 * LR_H) * (4 * LR_W) / 1e6
-    return {"value": round(mp / t, 4), "unit": "MP/s", "cores": threads, "kind": "port",
-            "sample": f"1 warm-up + 3 timed forwards of the same 16x3x96x96 batch, median {t:.2f} s, fp32, "
-                      f"torch {torch.__version__} CPU, torch.get_num_threads()={torch.get_num_threads()}"}
+    res = {"value": round(mp / t, 4), "unit": "MP/s", "cores": threads, "kind": "port",
+           "sample": f"1 warm-up + 3 timed forwards of the same 16x3x96x96 batch, median {t:.2f} s, fp32, "
+                     f"torch {torch.__version__} CPU, torch.get_num_threads()={torch.get_num_threads()}"}
+    if info:
+        res["cpu"] = info
+    return res
 
 
 def main():
@@ -139,8 +225,27 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as written: start the N ranks ourselves as FRESH child processes.  Nothing in
+        # this process has touched the GPU yet (no torch.cuda call above), and it never will: it only relays.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        child = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+        lines = [ln for ln in child.stdout.splitlines() if ln.startswith("{")]
+        for ln in child.stdout.splitlines():
+            if not ln.startswith("{"):
+                print(ln, file=sys.stderr)
+        if child.returncode != 0 or not lines:
+            raise SystemExit(child.returncode or 1)
+        print(lines[-1], flush=True)
+        return
     if args.gpus > 1 and world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch {args.gpus} ranks, or run without torch.distributed.run")
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -212,6 +317,7 @@ def main():
                     "mfma_family_tflops": round(f_fam / t_fam / 1e12, 2),
                     "whole_step_frac": round(value / world * 1e6 * FLOP_PER_OUT_PIXEL / 1e12 / peak, 4),
                     "sum_kernel_ms": round(float(kms.sum()), 4), "layers": layers,
+                    "hbm_bound_layers": hbm_bound_layers(plan, units, kms, gen, x),
                     "method": "HIP events (torch's current stream = the launch stream) around every launch of "
                               "instrumented forwards run right after the timed region, same process/data; achieved = "
                               "algorithmic conv FLOPs of the kernel's launches / their event time; traffic = FETCH_SIZE x2 "
@@ -227,9 +333,12 @@ def main():
                        "per_gpu_batch": BATCH, "lr": [LR_H, LR_W], "parallelism": f"batch-sharded x{world}, no collective"},
             "roofline": roofline,
         }
+        if world == 1 and args.compute == "bf16":
+            del gen                                   # plan buffers of the bf16 model are no longer needed
+            result["fp32_path"] = fp32_path(dev)
         if world == 1 and not args.no_cpu_baseline:
-            threads = max(1, min(16, os.cpu_count() or 1))
-            result["cpu_baseline"] = cpu_baseline(threads, sd_cpu, x_cpu)
+            info = host_cpu_info()
+            result["cpu_baseline"] = cpu_baseline(baseline_threads(info), sd_cpu, x_cpu, info)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -154,3 +154,20 @@ def lr_input(shape, seed=1, lo=-1.0, hi=1.0):
     """Synthetic LR batch U(lo,hi), NCHW float32 (dataset contract: P/dataset.py:40-47)."""
     r = np.random.Generator(np.random.PCG64([int(seed), 0xC0FFEE]))
     return np.ascontiguousarray(r.uniform(lo, hi, shape), dtype=np.float32)
+
+
+def randomise_module(m, seed):
+    """Seeded weights for the Keras-derived modules (srmi/keras_models.py), by parameter shape: conv W ~ N(0,
+    0.8/sqrt(fan_in)), bias ~ U(-0.1, 0.1), per-channel PReLU slopes ~ U(0.05, 0.4).  torch's CPU generator, so the
+    fixture script (oracle/make_golden_configs.py) and the GPU tests build identical weights."""
+    import torch
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for n, p in m.named_parameters():
+            if p.dim() == 4:
+                p.copy_(torch.randn(p.shape, generator=g) * (0.8 / (p.shape[1] * p.shape[2] * p.shape[3]) ** 0.5))
+            elif n.endswith("bias"):
+                p.copy_(torch.empty(p.shape).uniform_(-0.1, 0.1, generator=g))
+            else:
+                p.copy_(torch.empty(p.shape).uniform_(0.05, 0.4, generator=g))
+    return m

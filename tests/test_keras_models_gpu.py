@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from oracle import keras_oracle as K
+from oracle import weights as W
 from srmi.keras_models import SRCNN, AutoencoderSRGAN, KerasSRGAN, ResUNetSRGAN, RRDBNet, UNetSRGAN, from_keras_hwio
 
 pytestmark = pytest.mark.gpu
@@ -13,15 +14,7 @@ DEV = "cuda:0"
 
 
 def _randomise(m, seed):
-    g = torch.Generator().manual_seed(seed)
-    with torch.no_grad():
-        for n, p in m.named_parameters():
-            if p.dim() == 4:
-                p.copy_(torch.randn(p.shape, generator=g) * (0.8 / (p.shape[1] * p.shape[2] * p.shape[3]) ** 0.5))
-            elif n.endswith("bias"):
-                p.copy_(torch.empty(p.shape).uniform_(-0.1, 0.1, generator=g))
-            else:                                   # per-channel PReLU slopes
-                p.copy_(torch.empty(p.shape).uniform_(0.05, 0.4, generator=g))
+    W.randomise_module(m, seed)
 
 
 def _psnr01(a, b):
