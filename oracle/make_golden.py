@@ -227,7 +227,77 @@ def _put(out, prefix, name, t):
     out[f"{prefix}_absmax:{name}"] = flat.abs().max().item()
 
 
-def srgan_step_case(fname, num_block, batch, lr_hw, tv_coeff, wseed=0, xseed=31):
+def _reference_step_grads(num_block, patch, tv_coeff, g_np, d_np, v_np, lr, gt):
+    """D grads and G grads of one fine-tune iteration (P/mode.py:148-179) by the REFERENCE modules, fresh state."""
+    import torch.nn as nn
+    import torch.optim as optim
+    batch = lr.shape[0]
+    generator = Generator(num_block=num_block)
+    generator.load_state_dict(O.to_torch(g_np), strict=True)
+    generator.train()
+    discriminator = Discriminator(patch_size=patch)
+    discriminator.load_state_dict(O.to_torch(d_np), strict=True)
+    discriminator.train()
+    vgg_net = VggShaped(v_np).eval()
+    l2_loss, cross_ent, tv_loss = nn.MSELoss(), nn.BCELoss(), ref_losses.TVLoss()
+    g_optim = optim.Adam(generator.parameters(), lr=1e-4)
+    d_optim = optim.Adam(discriminator.parameters(), lr=1e-4)
+    VGG_loss = ref_losses.perceptual_loss(vgg_net)
+    real_label, fake_label = torch.ones((batch, 1)), torch.zeros((batch, 1))
+    output, _ = generator(lr)
+    fake_prob = discriminator(output)
+    real_prob = discriminator(gt)
+    d_loss = cross_ent(real_prob, real_label) + cross_ent(fake_prob, fake_label)
+    g_optim.zero_grad(); d_optim.zero_grad()
+    d_loss.backward()
+    dg = {n: p_.grad.clone() for n, p_ in discriminator.named_parameters()}
+    d_optim.step()
+    output, _ = generator(lr)
+    fake_prob = discriminator(output)
+    _percep_loss, hr_feat, sr_feat = VGG_loss((gt + 1.0) / 2.0, (output + 1.0) / 2.0, layer="relu5_4")
+    g_loss = 0.006 * _percep_loss + 1e-3 * cross_ent(fake_prob, real_label) + \
+        tv_coeff * tv_loss(0.006 * (hr_feat - sr_feat) ** 2) + l2_loss(output, gt)
+    g_optim.zero_grad(); d_optim.zero_grad()
+    g_loss.backward()
+    gg = {n: p_.grad.clone() for n, p_ in generator.named_parameters()}
+    return dg, gg
+
+
+def _sensitivity(out, num_block, patch, tv_coeff, g_np, d_np, v_np, lr, gt, base_dg, base_gg, trials):
+    """How far the REFERENCE's own fp32 gradients move when its inputs are perturbed at rounding level (every input
+    value multiplied by 1 + 1e-7 * N(0,1): one or two ulps): the spread that activation-kink flips and Adam's
+    sign(grad) first step cause in ANY fp32 implementation of this iteration.  Stored per gradient family as the worst
+    and the median per-tensor relative L2 change and the worst max-abs change (fraction of max|grad|), maximised over
+    `trials` perturbations.  The GPU tests gate srmi's distance from the reference at a small multiple of these."""
+    keysd = set(d_np.keys())
+    keysg = set(g_np.keys())
+
+    def bn_fed_bias(name, keys):
+        return name.endswith("body.0.bias") and name[:-len("0.bias")] + "1.running_mean" in keys
+
+    stats = {"dgrad": [0.0, 0.0, 0.0], "ggrad": [0.0, 0.0, 0.0]}
+    for t in range(trials):
+        gen = torch.Generator().manual_seed(9000 + t)
+        lr_p = lr * (1.0 + 1e-7 * torch.randn(lr.shape, generator=gen))
+        gt_p = gt * (1.0 + 1e-7 * torch.randn(gt.shape, generator=gen))
+        dg, gg = _reference_step_grads(num_block, patch, tv_coeff, g_np, d_np, v_np, lr_p, gt_p)
+        for fam, got, base, keys in (("dgrad", dg, base_dg, keysd), ("ggrad", gg, base_gg, keysg)):
+            l2, mx = [], []
+            for n, b in base.items():
+                if bn_fed_bias(n, keys):
+                    continue
+                d = (got[n] - b).double()
+                l2.append(float(d.norm()) / max(float(b.double().norm()), 1e-30))
+                mx.append(float(d.abs().max()) / max(float(b.abs().max()), 1e-30))
+            st = stats[fam]
+            st[0] = max(st[0], max(l2)); st[1] = max(st[1], sorted(l2)[len(l2) // 2]); st[2] = max(st[2], max(mx))
+        print(f"  sensitivity trial {t}: " + ", ".join(f"{k} l2max {v[0]:.2e} l2med {v[1]:.2e} absmax {v[2]:.2e}" for k, v in stats.items()))
+    for fam, st in stats.items():
+        out[f"sens_{fam}_l2max"], out[f"sens_{fam}_l2med"], out[f"sens_{fam}_absmax"] = st
+    out["sens_trials"] = trials
+
+
+def srgan_step_case(fname, num_block, batch, lr_hw, tv_coeff, wseed=0, xseed=31, sens_trials=6):
     """One fine-tune iteration, P/mode.py:148-179, run with the REFERENCE Generator, Discriminator,
     perceptual_loss, TVLoss (imported) and a VGG-shaped recipe-weight stack; mode.py itself cannot be imported
     (skimage / lpips / DISTS absent), so its loop body is restated line by line below."""
@@ -287,9 +357,11 @@ def srgan_step_case(fname, num_block, batch, lr_hw, tv_coeff, wseed=0, xseed=31)
     od_loss = d_part()
     od_loss.backward()
     _check("d_loss", d_loss.detach(), od_loss.detach(), tol=1e-6)
+    base_dg = {}
     for name, p_ in discriminator.named_parameters():
         _check("dgrad " + name[-24:], p_.grad, dsd[name].grad, tol=1e-5 * max(1.0, p_.grad.abs().max().item()))
         _put(out, "dgrad", name, p_.grad)
+        base_dg[name] = p_.grad.clone()
     d_optim.step()
     with torch.no_grad():                                   # move the oracle's D to the updated parameters
         for name, p_ in discriminator.named_parameters():
@@ -314,9 +386,11 @@ def srgan_step_case(fname, num_block, batch, lr_hw, tv_coeff, wseed=0, xseed=31)
     og_loss.backward()
     _check("g_loss", g_loss.detach(), og_loss.detach(), tol=2e-6 * max(1.0, abs(g_loss.item())))
     _check("percep", percep_loss.detach(), parts["percep"].detach(), tol=2e-6 * max(1.0, abs(percep_loss.item())))
+    base_gg = {}
     for name, p_ in generator.named_parameters():
         _check("ggrad " + name[-24:], p_.grad, gsd[name].grad, tol=2e-5 * max(1.0, p_.grad.abs().max().item()))
         _put(out, "ggrad", name, p_.grad)
+        base_gg[name] = p_.grad.clone()
     g_optim.step()
     out.update(d_loss=d_loss.item(), g_loss=g_loss.item(), percep_loss=percep_loss.item(),
                adversarial_loss=adversarial_loss.item(), total_variance_loss=total_variance_loss.item(),
@@ -352,6 +426,7 @@ def srgan_step_case(fname, num_block, batch, lr_hw, tv_coeff, wseed=0, xseed=31)
     g_part64()[0].backward()
     for name, _ in generator.named_parameters():
         _put(out, "ggrad64", name, g64[name].grad)
+    _sensitivity(out, num_block, patch, tv_coeff, g_np, d_np, v_np, lr, gt, base_dg, base_gg, sens_trials)
     for k in gstats:
         _check("G " + k[-28:], generator.state_dict()[k].double(), gstats[k].double(), tol=1e-5)
     for k in dstats:
@@ -419,6 +494,6 @@ if __name__ == "__main__":
     srgan_step_case("srgan_step_b8_lr16_tv.npz", 2, 8, 16, 2e-2, xseed=41)  # TV term switched on
     # the reference's DEFAULT configuration (P/main.py:12,14,21: res_num 16, batch_size 16, patch_size 24;
     # P/mode.py:128: Discriminator(patch_size=96)) = BASELINE config 3 per GPU
-    srgan_step_case("srgan_step_default_b16_lr24.npz", 16, 16, 24, 0.0, xseed=51)
+    srgan_step_case("srgan_step_default_b16_lr24.npz", 16, 16, 24, 0.0, xseed=51, sens_trials=4)
     # restore the process-wide shared PReLU to its default for anyone importing after us
     print("done ->", GOLD)

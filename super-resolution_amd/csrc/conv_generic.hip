@@ -12,24 +12,9 @@
 // K order inside a tap is permuted so each lane reads 4 consecutive channels (one 16-B load):
 // k-pair (c0+j, c0+4+j) is fed to MFMA j; A and B use the same permutation so the sum is the
 // same set of products.
-#include "common.h"
+#include "generic_common.h"
 
 namespace srmi {
-
-struct GenericParams {
-    const void* x; const float* w; const float* scale; const float* shift; const float* alpha;
-    const void* res; void* y;
-    int N, H, W, Cin, Cout, kh, kw, stride, pad;
-    int Ho, Wo, Cf, Hf, Wf, in_cs, out_cs, out_co, res_cs;
-    int in_bf16, out_bf16, res_bf16, in_nchw, out_nchw, vec_ok;
-    int act; float act_param; int alpha_pc; int r; int dcr;
-    int Cin_pad, Cout_pad, M;
-    hipStream_t stream;
-    int ksplit;      // > 1: grid.z slices of K (linear epilogue only: no scale / activation / residual)
-    float* partial;  // ksplit > 1: slice z STORES its partial tile at partial + z * partial_stride (same indexing
-    size_t partial_stride;  // as y) and generic_splitk_reduce_kernel adds the slices in index order: deterministic
-    int transposed;  // dgrad: gather dz at (o + pad - k) / stride where divisible
-};
 
 template <int NT>
 __global__ __launch_bounds__(256) void conv_generic_kernel(GenericParams p) {
@@ -118,48 +103,7 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(GenericParams p) {
         }
     }
 
-    // ---- fused epilogue: scale/shift -> act -> +residual -> (sub-pixel) store ---------------
-    const int rr = p.r * p.r;
-#pragma unroll
-    for (int t = 0; t < NT; ++t) {
-        const int co = co0 + 32 * t + i;
-        const bool cvalid = co < p.Cout;
-        const int coc = cvalid ? co : 0;
-        const float sc = p.scale ? p.scale[coc] : 1.f;
-        const float sh = (p.shift && (p.ksplit <= 1 || blockIdx.z == 0)) ? p.shift[coc] : 0.f;
-        const float al = (p.act == SRMI_ACT_PRELU) ? p.alpha[p.alpha_pc ? coc : 0] : 0.f;
-        int c = coc, si = 0, sj = 0;
-        if (p.r > 1) {
-            if (p.dcr) { c = coc % p.Cf; const int s = coc / p.Cf; si = s / p.r; sj = s % p.r; }
-            else { c = coc / rr; const int s = coc % rr; si = s / p.r; sj = s % p.r; }
-        }
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-            const int n_r = __shfl(n, row), oy_r = __shfl(oy, row), ox_r = __shfl(ox, row);
-            if (!cvalid || m0 + row >= p.M) continue;
-            const int Y = oy_r * p.r + si, X = ox_r * p.r + sj;
-            const bool late = p.act == SRMI_ACT_ADD_RELU;   // the residual joins before the ReLU
-            float val = late ? acc[t][e] * sc + sh : apply_act(acc[t][e] * sc + sh, p.act, p.act_param, al);
-            size_t oidx, ridx;
-            if (p.out_nchw) {
-                oidx = (((size_t)n_r * p.Cf + c) * p.Hf + Y) * p.Wf + X;
-                ridx = oidx;
-            } else {
-                const size_t px = ((size_t)n_r * p.Hf + Y) * p.Wf + X;
-                oidx = px * p.out_cs + p.out_co + c;
-                ridx = px * p.res_cs + c;
-            }
-            if (p.ksplit > 1) {
-                p.partial[(size_t)blockIdx.z * p.partial_stride + oidx] = val;
-                continue;
-            }
-            if (p.res) val += p.res_bf16 ? bf2f(((const bf16_t*)p.res)[ridx]) : ((const float*)p.res)[ridx];
-            if (late) val = fmaxf(val, 0.f);
-            if (p.out_bf16) ((bf16_t*)p.y)[oidx] = f2bf(val);
-            else ((float*)p.y)[oidx] = val;
-        }
-    }
+    generic_epilogue<NT>(p, acc, m0, co0, n, oy, ox, lane, blockIdx.z);
 }
 
 // OIHW f32 -> [tap][Cin_pad][Cout_pad] f32, zero padded
@@ -229,6 +173,11 @@ int generic_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, h
 
 static int generic_run(const struct GenericParams& p);
 
+// LDS-tiled kernel for NHWC f32 inputs (conv_f32_tiled.hip); this file's kernel serves the other input layouts / dtypes
+bool f32t_supported(const GenericParams& p);
+int f32t_ksplit(const GenericParams& p);
+int f32t_launch(const GenericParams& p);
+
 // y[i] = partial[0][i] + partial[1][i] + ... in slice order (slice 0 carries the shift)
 __global__ void generic_splitk_reduce_kernel(const float* __restrict__ partial, float* __restrict__ y, size_t n,
                                              int ksplit) {
@@ -254,6 +203,8 @@ static int generic_ksplit(const GenericParams& p) {
 
 static void generic_fill(GenericParams& p, const srmi_conv_args& a, const ConvGeom& g);
 
+static int pick_ksplit(const GenericParams& p) { return f32t_supported(p) ? f32t_ksplit(p) : generic_ksplit(p); }
+
 // bytes of workspace that make the forward conv's split-K deterministic (0: it does not split)
 size_t generic_workspace_bytes(const srmi_conv_desc& d, const ConvGeom& g) {
     srmi_conv_args a;
@@ -264,7 +215,7 @@ size_t generic_workspace_bytes(const srmi_conv_desc& d, const ConvGeom& g) {
     const long long M = (long long)d.N * g.Ho * g.Wo;
     if (M <= 0 || M > 0x7fffffffLL) return 0;
     p.M = (int)M;
-    const int ks = generic_ksplit(p);
+    const int ks = pick_ksplit(p);
     return ks > 1 ? (size_t)ks * d.N * g.Cf * g.Hf * g.Wf * sizeof(float) : 0;
 }
 
@@ -313,19 +264,25 @@ static int generic_run(const GenericParams& p0) {
     // scale and a dense f32 output, which is what the training path asks for, and a workspace: the slices are
     // stored there and added in slice order, so the result is the same bits on every run.  There are NO float
     // atomics in this file: without a (large enough) workspace the conv simply does not split.
-    p.ksplit = generic_ksplit(p);
+    const bool tiled = f32t_supported(p);
+    p.ksplit = pick_ksplit(p);
     const size_t out_elems = (size_t)p.N * p.Cf * p.Hf * p.Wf;
     if (p.ksplit > 1) {
         if (p.partial && p.partial_stride >= out_elems * (size_t)p.ksplit) p.partial_stride = out_elems;
         else { p.ksplit = 1; p.partial = nullptr; }
     }
     dim3 grid(gx, gy, (unsigned)p.ksplit);
-    if (p.Cout > 32) {
-        hipLaunchKernelGGL(conv_generic_kernel<2>, grid, dim3(256), 0, s, p);
+    int rc;
+    if (tiled) {
+        rc = f32t_launch(p);
     } else {
-        hipLaunchKernelGGL(conv_generic_kernel<1>, grid, dim3(256), 0, s, p);
+        if (p.Cout > 32) {
+            hipLaunchKernelGGL(conv_generic_kernel<2>, grid, dim3(256), 0, s, p);
+        } else {
+            hipLaunchKernelGGL(conv_generic_kernel<1>, grid, dim3(256), 0, s, p);
+        }
+        rc = hip_check(hipGetLastError(), "conv_generic_kernel");
     }
-    int rc = hip_check(hipGetLastError(), "conv_generic_kernel");
     if (rc || p.ksplit <= 1 || !p.partial) return rc;
     size_t blocks = (out_elems + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -343,7 +300,7 @@ size_t generic_dgrad_workspace_bytes(const srmi_conv_desc& d, const ConvGeom& g)
     const long long M = (long long)d.N * d.H * d.W;
     if (M <= 0 || M > 0x7fffffffLL) return 0;
     p.M = (int)M;
-    const int ks = generic_ksplit(p);
+    const int ks = pick_ksplit(p);
     return ks > 1 ? (size_t)ks * M * d.Cin * sizeof(float) : 0;
 }
 

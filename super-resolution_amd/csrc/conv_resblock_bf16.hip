@@ -622,11 +622,22 @@ int resblock_launch(const srmi_conv_args& a1, const srmi_conv_args& a2, hipStrea
     if (p.dbg & 1024) p.v.epi2.H = 0;            // ablation: epilogue arithmetic only (every pixel fails the bounds check: no loads, no stores)
     if (d1.N == 0 || d1.H == 0 || d1.W == 0) return SRMI_OK;
     const bool big = d1.W > 64 && d1.H >= 6;
+    // Tile shape of the big variant: 6 x 96 (conv1 region 8 x 98 = 49 pixel tiles -> 56 slots on 8 waves, halo tile 10 x 100)
+    // or 12 x 48 (region 14 x 50 = 44 tiles -> 48 slots, halo tile 16 x 52: 14 % fewer conv-1 MFMAs and 17 % less staging
+    // for the same 576 output pixels).  Cost = rounds of 256 workgroups x MFMA slots per workgroup (conv1 + conv2).
+    const long long nb96 = (long long)d1.N * ((d1.W + 95) / 96) * ((d1.H + 5) / 6);
+    const long long nb48 = (long long)d1.N * ((d1.W + 47) / 48) * ((d1.H + 11) / 12);
+    const bool t12 = big && d1.H >= 12 && !(p.dbg & (1 << 23)) &&
+                     ((nb48 + 255) / 256) * (48 + 40) <= ((nb96 + 255) / 256) * (56 + 40);
     if (big && (p.dbg & 4096)) {        // 6 x 48 tiles, two workgroups per CU
         p.tiles_x = (d1.W + 47) / 48; p.tiles_y = (d1.H + 5) / 6;
         const long long nb = (long long)d1.N * p.tiles_x * p.tiles_y;
         if (nb > 0x7fffffffLL) { set_error("resblock_bf16: grid too large"); return SRMI_EINVAL; }
         hipLaunchKernelGGL((resblock_c64_kernel<6, 3, 4, 3, 2, false, 1, 2>), dim3((unsigned)nb), dim3(256), 0, s, p);
+    } else if (t12) {
+        p.tiles_x = (d1.W + 47) / 48; p.tiles_y = (d1.H + 11) / 12;
+        if (nb48 > 0x7fffffffLL) { set_error("resblock_bf16: grid too large"); return SRMI_EINVAL; }
+        hipLaunchKernelGGL((resblock_c64_kernel<12, 3, 8, 4, 1, false, 1>), dim3((unsigned)nb48), dim3(512), 0, s, p);
     } else if (big) {
         p.tiles_x = (d1.W + 95) / 96; p.tiles_y = (d1.H + 5) / 6;
         const long long nb = (long long)d1.N * p.tiles_x * p.tiles_y;

@@ -125,6 +125,197 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradParams p, int NT
     }
 }
 
+// =====================================================================================================================
+// LDS-tiled weight gradient (the roofline kernel; the kernel above stays as the fallback for kw > 9).
+//
+//   dW[co][ci][ky][kx] = sum over flattened output pixels m of dz[m][co] * x[pixel(m) * stride - pad + (ky, kx)][ci]
+//
+// GEMM view per kernel row ky: M = Cout, N = (kx, ci), K = output pixels.  One workgroup (4 waves) owns CO output
+// channels x CT input channels x all KW taps of ONE ky and walks its slice of the pixels in chunks of 32: per chunk the
+// dz rows [32 px][CO] and the im2col'd input rows [32 px][KW][CT] (each (pixel, kx) is CT*4 contiguous bytes of the NHWC
+// tensor; zero for padding) go global -> registers -> LDS, double-buffered, one barrier per chunk.  Both LDS images are
+// pixel-major = K-major for the MFMA: every operand read is a conflict-free ds_read_b32 per 32 lanes.  A wave keeps KW
+// accumulator tiles of 32(co) x 32(ci): one dz read feeds KW MFMAs.  The 8 threads that share a pixel decode its
+// coordinates once per chunk.  Deterministic like the kernel above: a fixed pixel order inside the workgroup, partial
+// tiles through the caller's workspace when the pixels are split over workgroups, added in slice order.
+template <int KW, int WCO, int WCI>
+__global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradParams p, int chunks_per_slice, int M) {
+    static_assert(WCO * WCI == 4, "four waves");
+    constexpr int CO = WCO * 32, CT = WCI * 32;
+    constexpr int A_LOADS = CO / 4 / 8;                  // 16-B pieces per thread: 8 threads share a pixel
+    constexpr int B_LOADS = KW * CT / 4 / 8;
+    __shared__ __attribute__((aligned(16))) float As[2][32][CO];
+    __shared__ __attribute__((aligned(16))) float Bs[2][32][KW * CT];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int wco = wave / WCI, wci = wave % WCI;
+    int t = blockIdx.x;
+    const int cit = t % p.ci_tiles; t /= p.ci_tiles;
+    const int cot = t % p.co_tiles; t /= p.co_tiles;
+    const int ky = t;
+    const int co0 = cot * CO, ci0 = cit * CT;
+    const int kpx = tid >> 3, part = tid & 7;            // this thread's pixel of every chunk, and its share of that pixel's pieces
+    const int c_first = blockIdx.y * chunks_per_slice;
+    const int c_last = min(c_first + chunks_per_slice, (M + 31) / 32);
+    const bool a_vec = (p.Cout % 4 == 0) && (((uintptr_t)p.dz) % 16 == 0);
+    const bool b_vec = (p.Cin % 4 == 0) && (p.in_cs % 4 == 0) && (((uintptr_t)p.x) % 16 == 0);
+
+    f32x4 ra[A_LOADS], rb[B_LOADS];
+    auto load_chunk = [&](int c) {
+        const int m = c * 32 + kpx;
+        const bool mv = m < M;
+        const float* dzr = p.dz + (size_t)(mv ? m : 0) * p.Cout;
+#pragma unroll
+        for (int l = 0; l < A_LOADS; ++l) {
+            const int co = co0 + 4 * (part + 8 * l);
+            f32x4 q = {0.f, 0.f, 0.f, 0.f};
+            if (mv && co < p.Cout) {
+                if (a_vec) q = *(const f32x4*)(dzr + co);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (co + j < p.Cout) q[j] = dzr[co + j];
+                }
+            }
+            ra[l] = q;
+        }
+        const int mm = mv ? m : 0;
+        const int ox = mm % p.Wo;
+        const int tq = mm / p.Wo;
+        const int oy = tq % p.Ho, n = tq / p.Ho;
+        const int iy = oy * p.stride - p.pad + ky;
+        const bool rv = mv && iy >= 0 && iy < p.H;
+        const float* xrow = p.x + ((size_t)n * p.H + (rv ? iy : 0)) * p.W * p.in_cs;
+#pragma unroll
+        for (int l = 0; l < B_LOADS; ++l) {
+            const int q4 = part + 8 * l;                 // piece of this pixel's [KW][CT] row
+            const int kx = q4 / (CT / 4), ci = ci0 + 4 * (q4 % (CT / 4));
+            const int ix = ox * p.stride - p.pad + kx;
+            f32x4 q = {0.f, 0.f, 0.f, 0.f};
+            if (rv && ix >= 0 && ix < p.W && ci < p.Cin) {
+                const float* src = xrow + (size_t)ix * p.in_cs + ci;
+                if (b_vec) q = *(const f32x4*)src;
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (ci + j < p.Cin) q[j] = src[j];
+                }
+            }
+            rb[l] = q;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int l = 0; l < A_LOADS; ++l) *(f32x4*)&As[buf][kpx][4 * (part + 8 * l)] = ra[l];
+#pragma unroll
+        for (int l = 0; l < B_LOADS; ++l) *(f32x4*)&Bs[buf][kpx][4 * (part + 8 * l)] = rb[l];
+    };
+
+    f32x16 acc[KW];
+#pragma unroll
+    for (int u = 0; u < KW; ++u)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[u][e] = 0.f;
+
+    if (c_first < c_last) {
+        load_chunk(c_first);
+        store_chunk(0);
+    }
+    __syncthreads();
+    int buf = 0;
+    for (int c = c_first; c < c_last; ++c) {
+        const bool more = c + 1 < c_last;
+        if (more) load_chunk(c + 1);
+#pragma unroll
+        for (int kk = 0; kk < 16; ++kk) {
+            const int k = 2 * kk + h;
+            const float a = As[buf][k][wco * 32 + i];
+#pragma unroll
+            for (int u = 0; u < KW; ++u)
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, Bs[buf][k][u * CT + wci * 32 + i], acc[u], 0, 0, 0);
+        }
+        if (more) store_chunk(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
+
+    if (p.partial) {   // raw accumulators, lane-linear: [slice][tile][kx][wave][e][lane]
+        float* dst = p.partial + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * KW) * 4096 + wave * 1024 + lane;
+#pragma unroll
+        for (int u = 0; u < KW; ++u)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) dst[(size_t)u * 4096 + e * 64] = acc[u][e];
+        return;
+    }
+    const size_t taps = (size_t)p.kh * p.kw;
+    const int ci = ci0 + wci * 32 + i;
+    if (ci >= p.Cin) return;
+#pragma unroll
+    for (int u = 0; u < KW; ++u)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = co0 + wco * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (row < p.Cout) p.dw[((size_t)row * p.Cin + ci) * taps + (size_t)ky * p.kw + u] = acc[u][e];
+        }
+}
+
+// dw = sum over slices of the partial tiles of conv_wgrad2_kernel, in a FIXED association (deterministic): a workgroup
+// handles 32 elements, 8 threads per element take the slices y = g, g + 8, ... in order, and the 8 sub-sums are added
+// in g order through LDS.
+__global__ __launch_bounds__(256) void wgrad2_reduce_kernel(WgradParams p, int KW, int WCI, int tiles, int slices) {
+    __shared__ float part[8][32];
+    const size_t per_tile = (size_t)KW * 4096;
+    const size_t total = per_tile * tiles;
+    const int CO = (4 / WCI) * 32, CT = WCI * 32;
+    const int el = threadIdx.x & 31, g = threadIdx.x >> 5;
+    for (size_t base = (size_t)blockIdx.x * 32; base < total; base += (size_t)gridDim.x * 32) {   // total % 32 == 0
+        const size_t idx = base + el;
+        float v = 0.f;
+        for (int y = g; y < slices; y += 8) v += p.partial[(size_t)y * total + idx];
+        __syncthreads();
+        part[g][el] = v;
+        __syncthreads();
+        if (g != 0) continue;
+        v = part[0][el];
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v += part[r][el];
+        const int lane = (int)(idx & 63), e = (int)((idx >> 6) & 15), wave = (int)((idx >> 10) & 3);
+        const int u = (int)((idx >> 12) % KW);
+        int t = (int)(idx / per_tile);
+        const int cit = t % p.ci_tiles; t /= p.ci_tiles;
+        const int cot = t % p.co_tiles; t /= p.co_tiles;
+        const int ky = t;
+        const int wco = wave / WCI, wci = wave % WCI, i = lane & 31, h = lane >> 5;
+        const int row = cot * CO + wco * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        const int ci = cit * CT + wci * 32 + i;
+        if (row < p.Cout && ci < p.Cin)
+            p.dw[((size_t)row * p.Cin + ci) * ((size_t)p.kh * p.kw) + (size_t)ky * p.kw + u] = v;
+    }
+}
+
+// tiling / split plan of the tiled kernel, shared by the launch and the workspace query
+struct Wgrad2Plan { int KW, WCI, co_tiles, ci_tiles, slices, cps; long long tiles, M; };
+
+static bool wgrad2_plan(const srmi_conv_desc& d, const ConvGeom& g, bool allow_split, Wgrad2Plan* w) {
+    if (dbg_flags() & (1 << 25)) return false;
+    if (d.kw != 1 && d.kw != 3 && d.kw != 6 && d.kw != 9) return false;
+    w->KW = d.kw;
+    w->WCI = (d.Cin > 32 && d.kw <= 6) ? 2 : 1;               // CT = 64 (CO = 64) or CT = 32 (CO = 128)
+    const int CO = (4 / w->WCI) * 32, CT = w->WCI * 32;
+    w->co_tiles = (d.Cout + CO - 1) / CO;
+    w->ci_tiles = (d.Cin + CT - 1) / CT;
+    w->tiles = (long long)d.kh * w->co_tiles * w->ci_tiles;
+    w->M = (long long)d.N * g.Ho * g.Wo;
+    if (w->tiles > 0x7fffffffLL || w->M > 0x7fffffffLL || w->M == 0) return false;
+    const long long chunks = (w->M + 31) / 32;
+    long long slices = allow_split ? (512 + w->tiles - 1) / w->tiles : 1;
+    if (slices > (chunks + 3) / 4) slices = (chunks + 3) / 4;   // at least four chunks (128 pixels) per slice
+    if (slices < 1) slices = 1;
+    if (slices > 65535) slices = 65535;
+    w->cps = (int)((chunks + slices - 1) / slices);
+    w->slices = (int)((chunks + w->cps - 1) / w->cps);
+    return true;
+}
+
 // tiling / split plan shared by the launch and the workspace query
 struct WgradPlan { int NT, co_tiles, ci_tiles, rows, rows_per_split, gy; long long tiles; };
 
@@ -154,6 +345,8 @@ static int wgrad_plan(const srmi_conv_desc& d, const ConvGeom& g, bool allow_spl
 }
 
 size_t wgrad_workspace_bytes(const srmi_conv_desc& d, const ConvGeom& g) {
+    Wgrad2Plan w2;
+    if (wgrad2_plan(d, g, true, &w2)) return w2.slices > 1 ? (size_t)w2.slices * w2.tiles * w2.KW * 4096 * sizeof(float) : 0;
     WgradPlan w;
     if (wgrad_plan(d, g, true, &w) || w.rows == 0 || g.Wo == 0) return 0;
     return w.gy > 1 ? (size_t)w.gy * w.tiles * w.NT * 1024 * sizeof(float) : 0;
@@ -165,6 +358,32 @@ int wgrad_launch(const srmi_conv_desc& d, const ConvGeom& g, const float* x, con
     p.x = x; p.dz = dz; p.dw = dw; p.partial = nullptr;
     p.N = d.N; p.H = d.H; p.W = d.W; p.Cin = d.Cin; p.Cout = d.Cout; p.kh = d.kh; p.kw = d.kw;
     p.stride = d.stride; p.pad = d.pad; p.Ho = g.Ho; p.Wo = g.Wo; p.in_cs = g.in_cs;
+    Wgrad2Plan w2;
+    if (wgrad2_plan(d, g, true, &w2)) {
+        if (w2.slices > 1) {
+            const size_t need = (size_t)w2.slices * w2.tiles * w2.KW * 4096 * sizeof(float);
+            if (ws && ws_bytes >= need) p.partial = (float*)ws;
+            else wgrad2_plan(d, g, false, &w2);              // no workspace: one workgroup per tile walks every pixel
+        }
+        p.rows = 0; p.rows_per_split = 0; p.co_tiles = w2.co_tiles; p.ci_tiles = w2.ci_tiles;
+        dim3 grid((unsigned)w2.tiles, (unsigned)w2.slices);
+        const int M = (int)w2.M;
+#define SRMI_WG2(KWv, WCOv, WCIv) hipLaunchKernelGGL((conv_wgrad2_kernel<KWv, WCOv, WCIv>), grid, dim3(256), 0, s, p, w2.cps, M)
+        if (w2.WCI == 2) {
+            if (w2.KW == 1) SRMI_WG2(1, 2, 2); else if (w2.KW == 3) SRMI_WG2(3, 2, 2); else SRMI_WG2(6, 2, 2);
+        } else {
+            if (w2.KW == 1) SRMI_WG2(1, 4, 1); else if (w2.KW == 3) SRMI_WG2(3, 4, 1);
+            else if (w2.KW == 6) SRMI_WG2(6, 4, 1); else SRMI_WG2(9, 4, 1);
+        }
+#undef SRMI_WG2
+        int rc2 = hip_check(hipGetLastError(), "conv_wgrad2_kernel");
+        if (rc2 || !p.partial) return rc2;
+        const size_t total = (size_t)w2.tiles * w2.KW * 4096;
+        size_t blocks = total / 32;
+        if (blocks > 16384) blocks = 16384;
+        hipLaunchKernelGGL(wgrad2_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, w2.KW, w2.WCI, (int)w2.tiles, w2.slices);
+        return hip_check(hipGetLastError(), "wgrad2_reduce_kernel");
+    }
     WgradPlan w;
     int rc = wgrad_plan(d, g, true, &w);
     if (rc) return rc;
