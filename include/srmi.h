@@ -276,7 +276,8 @@ int srmi_y_psnr_ssim_batch(const float* sr, const float* gt, int32_t n_images, i
  * the batch statistics of the whole conv output before it can normalise (P/ops.py:24-26 with the module in
  * .train(), P/mode.py:101, :149, :164):   z = conv(x) + bias  (srmi_conv2d_fwd, act NONE)  ->  batch stats  ->
  * y = store(act(bn(z))) + residual.  All tensors dense NHWC f32.  `ws` must hold srmi_train_workspace_bytes(C)
- * bytes (f64 per-channel accumulators), 8-byte aligned. */
+ * bytes, 8-byte aligned: the per-channel reductions leave one f64 partial per workgroup and channel there and a
+ * finalize launch adds them in a fixed order (no atomics: same input => same bits); it needs no clearing. */
 typedef struct srmi_epi_desc {
     int32_t N, H, W, C;        /* geometry of z, the conv output BEFORE any sub-pixel shuffle */
     int32_t act;               /* SRMI_ACT_* */

@@ -45,6 +45,7 @@ int tv_loss(const float* x, int N, int C, int H, int W, float weight, float* out
 int y_metrics(const float* sr, const float* gt, int nimg, int H, int W, int gt_H, int gt_W, int border, int clip,
               int win, double* out, void* ws, hipStream_t s);
 
+size_t train_workspace_bytes(int C);
 int bn_train_stats(const float* z, long long M, int C, float eps, float momentum, float* mean, float* rstd,
                    float* rmean, float* rvar, void* ws, hipStream_t s);
 int epilogue_fwd(const srmi_epi_desc& d, const float* z, const float* mean, const float* rstd, const float* gamma,
@@ -449,7 +450,7 @@ static int epi_check(const char* what, const srmi_epi_desc* d) {
 
 int srmi_train_workspace_bytes(int32_t C, size_t* bytes) {
     if (C <= 0 || !bytes) { set_error("train_workspace_bytes: bad arguments"); return SRMI_EINVAL; }
-    *bytes = (size_t)3 * C * sizeof(double);
+    *bytes = train_workspace_bytes(C);
     return SRMI_OK;
 }
 

@@ -2,20 +2,23 @@
 // the conv epilogue (normalise -> activation -> sub-pixel store -> residual) forward and backward,
 // 2x2 max-pool forward/backward, MSE/BCE loss gradients and the Adam update.
 //
-// Tensors are dense NHWC f32.  Per-channel sums use lanes along the channel axis (coalesced rows),
-// four waves along pixels, an LDS tree across the waves and one f64 global atomic per channel and
-// workgroup; the f64 accumulators live in the caller's workspace.
+// Tensors are dense NHWC f32.  Per-channel sums use lanes along the channel axis (coalesced rows), four waves along
+// pixels and an LDS tree across the waves; every workgroup then STORES its f64 partial sums in its own slot of the
+// caller's workspace and a finalize launch adds the slots in index order.  No atomics: the same input gives the
+// same bits on every run (tests/test_srgan_step_gpu.py::test_srgan_step_is_bit_reproducible).
 #include "common.h"
 
 namespace srmi {
 
 constexpr int CH_BLOCK = 256;
+constexpr int TRAIN_MAX_SLOTS = 128;      // partial slots per channel in the workspace (srmi_train_workspace_bytes)
 
 struct EpiParams {
     const float* z; const float* dy; const float* mean; const float* rstd; const float* gamma; const float* beta;
     const float* alpha; const float* residual;
     float* y; float* dz;
-    double* acc;  // [3][C] : S1, S2, dalpha (dalpha uses [Cf] or [1])
+    double* acc;  // partial slots [gridDim.x][3][C] (S1, S2, per-conv-channel dalpha terms), then the totals [3][C]
+    int nslots;   // gridDim.x of the reducing launch
     long long M;  // pixels N*H*W
     int H, W, C, Cf, r, dcr, act, alpha_pc, bn;
     float act_param;
@@ -60,19 +63,48 @@ __global__ __launch_bounds__(CH_BLOCK) void bn_stats_kernel(const float* __restr
     if (ty == 0 && c < C) {
         s1 = l1[tx] + l1[tx + 64] + l1[tx + 128] + l1[tx + 192];
         s2 = l2[tx] + l2[tx + 64] + l2[tx + 128] + l2[tx + 192];
-        atomicAdd(acc + c, s1);
-        atomicAdd(acc + C + c, s2);
+        acc[((size_t)blockIdx.x * 2) * C + c] = s1;
+        acc[((size_t)blockIdx.x * 2 + 1) * C + c] = s2;
     }
 }
 
 // mean, 1/sqrt(var+eps) and the running-statistics update of nn.BatchNorm2d (momentum, unbiased running var)
-__global__ void bn_finalize_kernel(const double* __restrict__ acc, long long M, int C, float eps, float momentum,
-                                   float* __restrict__ mean, float* __restrict__ rstd, float* __restrict__ rmean,
-                                   float* __restrict__ rvar) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    const double mu = acc[c] / (double)M;
-    double var = acc[C + c] / (double)M - mu * mu;
+// sum of the partial slots of channel c, array k of KA: 8 threads per channel take the slots g, g + 8, ... in order and
+// the 8 sub-sums are added in g order (a fixed association: deterministic).  Block = 32 channels x 8 groups.
+template <int KA>
+__device__ __forceinline__ void slot_sums(const double* __restrict__ acc, int nslots, int C, int c, int g, double (&t)[KA],
+                                          double (*sh)[8][32]) {
+#pragma unroll
+    for (int k = 0; k < KA; ++k) t[k] = 0.0;
+    if (c < C)
+        for (int b = g; b < nslots; b += 8)
+#pragma unroll
+            for (int k = 0; k < KA; ++k) t[k] += acc[((size_t)b * KA + k) * C + c];
+    const int cl = threadIdx.x & 31;
+#pragma unroll
+    for (int k = 0; k < KA; ++k) sh[k][g][cl] = t[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KA; ++k) {
+        double a = 0.0;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) a += sh[k][r][cl];
+        t[k] = a;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ acc, int nslots, long long M, int C,
+                                                          float eps, float momentum, float* __restrict__ mean,
+                                                          float* __restrict__ rstd, float* __restrict__ rmean,
+                                                          float* __restrict__ rvar) {
+    __shared__ double sh[2][8][32];
+    const int c = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+    double t[2];
+    slot_sums<2>(acc, nslots, C, c, g, t, sh);
+    if (c >= C || g != 0) return;
+    const double t1 = t[0], t2 = t[1];
+    const double mu = t1 / (double)M;
+    double var = t2 / (double)M - mu * mu;
     if (var < 0.0) var = 0.0;
     mean[c] = (float)mu;
     rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -106,7 +138,6 @@ __global__ __launch_bounds__(CH_BLOCK) void epilogue_bwd_kernel(EpiParams p) {
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
     const int c = blockIdx.y * 64 + tx;
     double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int cf_thread = 0;
     if (c < p.C) {
         float mu = 0.f, rs = 1.f, ga = 1.f, be = 0.f;
         if (p.bn) { mu = p.mean[c]; rs = p.rstd[c]; ga = p.gamma[c]; be = p.beta[c]; }
@@ -117,7 +148,6 @@ __global__ __launch_bounds__(CH_BLOCK) void epilogue_bwd_kernel(EpiParams p) {
             const float u = p.bn ? zh * ga + be : zh;
             int cf;
             const size_t o = final_index(p, m, c, &cf);
-            cf_thread = cf;
             const float g0 = p.dy[o];
             float g;
             switch (p.act) {
@@ -138,24 +168,11 @@ __global__ __launch_bounds__(CH_BLOCK) void epilogue_bwd_kernel(EpiParams p) {
     }
     l1[threadIdx.x] = s1; l2[threadIdx.x] = s2; l3[threadIdx.x] = s3;
     __syncthreads();
-    if (ty == 0) {
-        const bool cv = c < p.C;
-        s1 = l1[tx] + l1[tx + 64] + l1[tx + 128] + l1[tx + 192];
-        s2 = l2[tx] + l2[tx + 64] + l2[tx + 128] + l2[tx + 192];
-        s3 = cv ? l3[tx] + l3[tx + 64] + l3[tx + 128] + l3[tx + 192] : 0.0;
-        if (cv) atomicAdd(p.acc + c, s1);
-        if (cv && p.bn) atomicAdd(p.acc + p.C + c, s2);
-        if (p.act == SRMI_ACT_PRELU) {
-            if (p.alpha_pc) {
-                if (cv) atomicAdd(p.acc + 2 * p.C + cf_thread, s3);
-            } else {
-                // one shared slope: every channel adds to the SAME accumulator - reduce the 64 lanes first, or
-                // tens of thousands of same-address atomics serialise (they were 60 % of this kernel's time)
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) s3 += __shfl_down(s3, off);
-                if (tx == 0) atomicAdd(p.acc + 2 * p.C, s3);
-            }
-        }
+    if (ty == 0 && c < p.C) {
+        double* slot = p.acc + (size_t)blockIdx.x * 3 * p.C;
+        slot[c] = l1[tx] + l1[tx + 64] + l1[tx + 128] + l1[tx + 192];
+        slot[p.C + c] = l2[tx] + l2[tx + 64] + l2[tx + 128] + l2[tx + 192];
+        slot[2 * p.C + c] = l3[tx] + l3[tx + 64] + l3[tx + 128] + l3[tx + 192];    // dalpha terms of CONV channel c
     }
 }
 
@@ -167,21 +184,58 @@ __global__ __launch_bounds__(CH_BLOCK) void bn_bwd_apply_kernel(EpiParams p) {
         const int c = (int)(idx - (idx / (unsigned)p.C) * p.C);
         const float rs = p.rstd[c];
         const float zh = (p.z[idx] - p.mean[c]) * rs;
-        const float m1 = (float)(p.acc[c] * invM), m2 = (float)(p.acc[p.C + c] * invM);
+        const double* tot = p.acc + (size_t)p.nslots * 3 * p.C;       // totals, written by the finalize launch
+        const float m1 = (float)(tot[c] * invM), m2 = (float)(tot[p.C + c] * invM);
         p.dz[idx] = p.gamma[c] * rs * (p.dz[idx] - m1 - zh * m2);
     }
 }
 
-// f64 accumulators -> f32 parameter gradients
-__global__ void epilogue_bwd_finalize_kernel(const double* __restrict__ acc, int C, int n_alpha, int bn,
-                                             float* __restrict__ dsum1, float* __restrict__ dsum2,
-                                             float* __restrict__ dalpha) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C) {
-        if (dsum1) dsum1[c] = (float)acc[c];
-        if (bn && dsum2) dsum2[c] = (float)acc[C + c];
+// partial slots -> totals (kept for bn_bwd_apply_kernel) and f32 parameter gradients, all sums in a fixed order.
+// Workgroups 0 .. ceil(C/32)-1: 32 channels each (slot_sums).  The LAST workgroup produces dalpha from the slots:
+// per-channel slopes (n_alpha = Cf): thread cf adds the conv channels that store to final channel cf, slot by slot;
+// one shared slope (n_alpha = 1): 256 threads each add a strided share of the channels in order, then thread 0 adds
+// the 256 shares in order.
+__global__ __launch_bounds__(256) void epilogue_bwd_finalize_kernel(double* __restrict__ acc, int nslots, int C,
+                                                                    int n_alpha, int bn, int Cf, int rr, int dcr,
+                                                                    float* __restrict__ dsum1, float* __restrict__ dsum2,
+                                                                    float* __restrict__ dalpha) {
+    __shared__ double sh3[3][8][32];
+    __shared__ double sh[256];
+    double* tot = acc + (size_t)nslots * 3 * C;
+    if (blockIdx.x + 1 < gridDim.x) {
+        const int c = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+        double t[3];
+        slot_sums<3>(acc, nslots, C, c, g, t, sh3);
+        if (c >= C || g != 0) return;
+        tot[c] = t[0]; tot[C + c] = t[1]; tot[2 * C + c] = t[2];        // [2]: dalpha terms per conv channel
+        if (dsum1) dsum1[c] = (float)t[0];
+        if (bn && dsum2) dsum2[c] = (float)t[1];
+        return;
     }
-    if (dalpha && c < n_alpha) dalpha[c] = (float)acc[2 * C + c];
+    if (!dalpha || n_alpha <= 0) return;
+    if (n_alpha > 1) {          // per-channel slopes: final channel cf <- conv channels {cf*rr + s} (CRD) or {s*Cf + cf} (DCR)
+        for (int cf = threadIdx.x; cf < n_alpha; cf += 256) {
+            double t = 0.0;
+            for (int s = 0; s < rr; ++s) {
+                const int c = dcr ? s * Cf + cf : cf * rr + s;
+                for (int b = 0; b < nslots; ++b) t += acc[(size_t)b * 3 * C + 2 * C + c];
+            }
+            dalpha[cf] = (float)t;
+        }
+        return;
+    }
+    double t = 0.0;
+    for (long long it = threadIdx.x; it < (long long)nslots * C; it += 256) {      // item = (slot, channel), fixed order per thread
+        const int b = (int)(it / C), c = (int)(it - (long long)b * C);
+        t += acc[(size_t)b * 3 * C + 2 * C + c];
+    }
+    sh[threadIdx.x] = t;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0.0;
+        for (int k = 0; k < 256; ++k) a += sh[k];
+        dalpha[0] = (float)a;
+    }
 }
 
 // ---- 2x2 stride-2 max pool (VGG19, P/vgg19.py) NHWC f32 -------------------------------------------------
@@ -293,23 +347,28 @@ static unsigned ew_blocks(size_t total) {
     return (unsigned)b;
 }
 
+// grid of the per-channel reductions: x = pixel slices (each leaves one partial slot: at most TRAIN_MAX_SLOTS),
+// y = 64-channel groups; ~1024 workgroups in total
 static dim3 ch_grid(long long M, int C) {
     long long bx = (M + 63) / 64;  // >= 16 pixels per wave
-    const long long cap = 4096 / ((C + 63) / 64);    // ~4096 workgroups in total
+    long long cap = 1024 / ((C + 63) / 64);
+    if (cap < 16) cap = 16;
+    if (cap > TRAIN_MAX_SLOTS) cap = TRAIN_MAX_SLOTS;
     if (bx > cap) bx = cap;
     if (bx < 1) bx = 1;
     return dim3((unsigned)bx, (unsigned)((C + 63) / 64));
 }
 
+size_t train_workspace_bytes(int C) { return ((size_t)TRAIN_MAX_SLOTS * 3 + 3) * C * sizeof(double); }
+
 int bn_train_stats(const float* z, long long M, int C, float eps, float momentum, float* mean, float* rstd,
                    float* rmean, float* rvar, void* ws, hipStream_t s) {
-    int rc = hip_check(hipMemsetAsync(ws, 0, (size_t)2 * C * sizeof(double), s), "bn_stats memset");
+    const dim3 grid = ch_grid(M, C);      // every slot of the grid is written: nothing to clear
+    hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(CH_BLOCK), 0, s, z, M, C, (double*)ws);
+    int rc = hip_check(hipGetLastError(), "bn_stats_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_stats_kernel, ch_grid(M, C), dim3(CH_BLOCK), 0, s, z, M, C, (double*)ws);
-    rc = hip_check(hipGetLastError(), "bn_stats_kernel");
-    if (rc) return rc;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, s, (const double*)ws, M, C, eps, momentum,
-                       mean, rstd, rmean, rvar);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, (const double*)ws, (int)grid.x, M, C,
+                       eps, momentum, mean, rstd, rmean, rvar);
     return hip_check(hipGetLastError(), "bn_finalize_kernel");
 }
 
@@ -340,21 +399,24 @@ int epilogue_bwd(const srmi_epi_desc& d, const float* z, const float* dy, const 
     p.z = z; p.dy = dy; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.alpha = alpha;
     p.dz = dz; p.acc = (double*)ws;
     const int n_alpha = d.act == SRMI_ACT_PRELU ? (d.alpha_per_channel ? p.Cf : 1) : 0;
-    int rc = hip_check(hipMemsetAsync(ws, 0, (size_t)3 * d.C * sizeof(double), s), "epilogue_bwd memset");
-    if (rc) return rc;
+    const dim3 grid = ch_grid(p.M > 0 ? p.M : 1, p.C);
+    p.nslots = p.M > 0 ? (int)grid.x : 0;
+    int rc;
     if (p.M > 0) {
-        hipLaunchKernelGGL(epilogue_bwd_kernel, ch_grid(p.M, p.C), dim3(CH_BLOCK), 0, s, p);
+        hipLaunchKernelGGL(epilogue_bwd_kernel, grid, dim3(CH_BLOCK), 0, s, p);
         rc = hip_check(hipGetLastError(), "epilogue_bwd_kernel");
         if (rc) return rc;
-        if (d.bn) {
-            hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks((size_t)p.M * p.C)), dim3(CH_BLOCK), 0, s, p);
-            rc = hip_check(hipGetLastError(), "bn_bwd_apply_kernel");
-            if (rc) return rc;
-        }
     }
-    hipLaunchKernelGGL(epilogue_bwd_finalize_kernel, dim3((d.C + 255) / 256), dim3(256), 0, s, (const double*)ws, d.C,
-                       n_alpha, d.bn, dsum1, dsum2, dalpha);
-    return hip_check(hipGetLastError(), "epilogue_bwd_finalize_kernel");
+    // totals + parameter gradients (zero slots: all sums are zero)
+    hipLaunchKernelGGL(epilogue_bwd_finalize_kernel, dim3((d.C + 31) / 32 + 1), dim3(256), 0, s, (double*)ws, p.nslots,
+                       d.C, n_alpha, d.bn, p.Cf, d.shuffle * d.shuffle, p.dcr, dsum1, dsum2, dalpha);
+    rc = hip_check(hipGetLastError(), "epilogue_bwd_finalize_kernel");
+    if (rc) return rc;
+    if (p.M > 0 && d.bn) {
+        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks((size_t)p.M * p.C)), dim3(CH_BLOCK), 0, s, p);
+        return hip_check(hipGetLastError(), "bn_bwd_apply_kernel");
+    }
+    return SRMI_OK;
 }
 
 int maxpool_fwd(const float* x, float* y, int N, int H, int W, int C, hipStream_t s) {

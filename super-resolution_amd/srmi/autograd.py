@@ -77,6 +77,9 @@ def _ptr(t):
     return t.data_ptr() if t is not None else None
 
 
+_POISON = bool(int(__import__("os").environ.get("SRMI_POISON_WS", "0")))
+
+
 class _Workspace:
     """One growing device buffer per (device, stream) for the split-K slices of fwd / dgrad / wgrad.  Kernels that
     use it are enqueued on that stream and consume it before the next one starts, so sharing is ordered."""
@@ -91,10 +94,19 @@ class _Workspace:
         t = self.bufs.get(key)
         if t is None or t.numel() < nbytes:
             t = self.bufs[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        if _POISON:        # SRMI_POISON_WS=1 (tests): NaN-fill before every use - a kernel that reads a slot it did not write shows
+            t.view(torch.float32).fill_(float("nan"))
         return t
 
 
 _WS = _Workspace()
+_WS_TRAIN = _Workspace()      # f64 partial slots of the per-channel reductions (BN statistics, epilogue backward)
+
+
+def _train_ws(C_, device):
+    n = C.c_size_t(0)
+    L.check(L.load().srmi_train_workspace_bytes(C_, C.byref(n)))
+    return _WS_TRAIN.get(n.value, device)
 
 
 class _PackCache:
@@ -168,7 +180,7 @@ class FusedConvFn(torch.autograd.Function):
                 raise ValueError("srmi: train-mode BatchNorm over an empty batch")
             mean = torch.empty(Cout, dtype=torch.float32, device=dev)
             rstd = torch.empty(Cout, dtype=torch.float32, device=dev)
-            ws = torch.empty(3 * Cout, dtype=torch.float64, device=dev)
+            ws = _train_ws(Cout, dev)
             track = bn.track_running_stats and bn.running_mean is not None
             if bn.momentum is None:
                 raise NotImplementedError("srmi: BatchNorm2d(momentum=None) (cumulative average) is not supported")
@@ -205,7 +217,7 @@ class FusedConvFn(torch.autograd.Function):
         dy = nhwc(dy)
         Cout = desc.Cout
         dz = torch.empty_like(z)
-        ws = torch.empty(3 * Cout, dtype=torch.float64, device=dev)
+        ws = _train_ws(Cout, dev)
         dsum1 = torch.empty(Cout, dtype=torch.float32, device=dev)
         dsum2 = torch.empty(Cout, dtype=torch.float32, device=dev) if cfg.bn is not None else None
         dalpha = torch.empty_like(alpha) if alpha is not None else None
