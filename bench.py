@@ -99,7 +99,7 @@ def per_kernel_times(gen, x, reps):
         ev[0].record()
         for u, (label, i, cnt) in enumerate(units):
             if cnt == 2:
-                L.check(lib.srmi_resblock_fwd(C.byref(plan.args[i]), C.byref(plan.args[i + 1]), st))
+                L.check(lib.srmi_conv2d_fwd_pair(C.byref(plan.args[i]), C.byref(plan.args[i + 1]), st))
             else:
                 L.check(lib.srmi_conv2d_fwd(C.byref(plan.args[i]), st))
             ev[u + 1].record()

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SRMI_VERSION 110 /* 0.1.1: dgrad / wgrad take a workspace (deterministic split-K), no float atomics left */
+#define SRMI_VERSION 111 /* 0.1.1: dgrad / wgrad take a workspace (deterministic split-K), no float atomics left */
 
 /* error codes */
 #define SRMI_OK 0
@@ -166,8 +166,21 @@ int srmi_chain_status(uint32_t* timeouts);
  * (P/ops.py:45-48). */
 int srmi_resblock_fwd(const srmi_conv_args* conv1, const srmi_conv_args* conv2, void* stream);
 
-/* 1 if srmi_conv2d_fwd_seq would run (conv1 flagged SRMI_CONV_FUSE_NEXT, conv2) as one fused launch, else 0. */
+/* Non-zero if srmi_conv2d_fwd_seq would run (conv1 flagged SRMI_CONV_FUSE_NEXT, conv2) as one fused launch:
+ * SRMI_FUSE_RESBLOCK (the pair above) or SRMI_FUSE_UPTAIL (below); 0 if they go out as two launches. */
+#define SRMI_FUSE_RESBLOCK 1
+#define SRMI_FUSE_UPTAIL 2
 int srmi_conv2d_can_fuse(const srmi_conv_args* conv1, const srmi_conv_args* conv2);
+
+/* Any fusable pair in one launch (the kind srmi_conv2d_can_fuse reports); SRMI_EUNSUPPORTED otherwise.
+ * SRMI_FUSE_UPTAIL is the generator's tail: conv1 = conv3x3 64->256 + PixelShuffle(2) (CRD order) + shared-slope
+ * activation, NHWC bf16 in; conv2 = conv3x3 64->3 + any pointwise activation, NCHW f32 out, on conv1's output
+ * (conv2->d.H/W = 2x conv1's).  conv1's output tensor is never written: conv1->y is ignored (may be any non-aliasing
+ * pointer), conv2->x is ignored.  The last conv's nine tap sums are accumulated in int32 fixed point (2^-18 units)
+ * in LDS, so the result is the same for every run and every tiling; it differs from the two-launch path by that
+ * quantisation (<= 2e-5 on the pre-activation) and by f32 summation order only.  Replaces the second `Upsampler`
+ * + `last_conv` + tanh of `Generator.forward` (P/ops.py:74-78, P/srgan_model.py:36-37). */
+int srmi_conv2d_fwd_pair(const srmi_conv_args* conv1, const srmi_conv_args* conv2, void* stream);
 
 /* dense tensor re-layout / cast: src (N,C,H,W logical) in (src_layout, src_dtype) -> dst.
  * Replaces the implicit NCHW contract at the module edge (P/dataset.py:46-47, P/mode.py:396-400). */

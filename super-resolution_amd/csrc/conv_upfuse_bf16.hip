@@ -1,0 +1,363 @@
+// Fused tail of the generator: conv3x3(64 -> 256) -> PixelShuffle(2) -> PReLU -> conv3x3(64 -> 3) -> Tanh in ONE launch
+// (the second Upsampler and last_conv, P/ops.py:74-78 and P/srgan_model.py:25,36-37), NHWC bf16 in, NCHW f32 out.
+//
+// Why: unfused, the up conv writes the 64-channel tensor T at 4x resolution (302 MB at config 1) and the thin last conv
+// reads it back: ~760 MB of HBM traffic per forward where ~105 MB is compulsory, and 230 us of the 0.8 ms step.  Here T
+// never leaves the chip - it does not even reach LDS:
+//
+//   * the up conv is conv_c64_kernel's machinery (LDS-resident swizzled input halo tile, weights through an LDS-DMA
+//     ring, 16 x 16 x 32 bf16 MFMAs, 8 waves).  Every output pixel of the last conv needs T one pixel around it, so a
+//     workgroup needs T on its 2TH x 2TW output tile plus a one-pixel ring IN T SPACE - which is only HALF an up-conv
+//     pixel: sub-pixel (si, sj) of PixelShuffle(2) is needed on up-conv rows [y0 - si, y0 + TH - si] and columns
+//     [x0 - sj, x0 + TW - sj], a (TH + 1) x (TW + 1) region per sub-pixel instead of (TH + 2) x (TW + 2).  With a 24 x 24
+//     tile that is 625 pixels = 40 MFMA pixel tiles (5 per wave) for 576 useful ones: 1.11x the up conv's MFMAs is the
+//     price of never storing T (the ring is recomputed by neighbouring workgroups);
+//   * one 64-channel chunk of the up conv's output IS one sub-pixel (i, j) of PixelShuffle(2) with all 64 channels of T
+//     (CRD order: conv channel = 4 c + 2 i + j), and the accumulator layout of the MFMA gives a lane 16 channels of one
+//     pixel - after bias + PReLU + bf16 rounding (the same values the unfused path stores) these registers ARE the B
+//     operand of the last conv's MFMA, with no data movement;
+//   * the last conv runs in SCATTER form: for a T pixel, M = 27 rows (9 taps x 3 output channels), K = 64 channels:
+//     4 MFMAs per pixel tile and chunk (+5.5 % MFMAs; the gather form would need 18).  Each of the 27 results belongs to
+//     the output pixel one tap away and is added to a (2TH+4) x (2TW+4) x 3 accumulation image in LDS;
+//   * that accumulation is in FIXED POINT (int32, 2^-18 units, ds_add_u32): integer addition is associative, so the
+//     result does not depend on the order in which waves reach the adds - same bits on every run and for every tiling
+//     of the image (float LDS atomics would not give that).  Resolution 3.8e-6 on the pre-tanh value, nine adds per
+//     output: far below the bf16 rounding of T;
+//   * at the end the workgroup converts its 2TH x 2TW x 3 outputs: scale/shift (bias), tanh, NCHW f32 stores.
+//
+// Algorithmic bytes: 128 B (bf16 input pixel at 2x) per 4 output pixels + 12 B per output pixel written.
+#include <type_traits>
+
+#include "c64_common.h"
+
+namespace srmi {
+
+struct UpFuseParams {
+    const bf16_t* x; const bf16_t* w;      // up conv input (NHWC bf16) and its c64-packed weights (CRD store mode)
+    C64Epi epi;                            // up conv scale / shift / slope (res, y unused)
+    const bf16_t* w7;                      // last conv weights as packed by thin_pack: [tap][k half][lane][8] bf16, rows = out channel
+    const float* scale7; const float* shift7; const float* alpha7;
+    float* y;                              // [N, 3, 4H', 4W'] f32 where the up conv runs at H x W = 2H' x 2W'
+    int N, H, W, in_cs;                    // up conv geometry
+    int tiles_x, tiles_y;
+    int act7; float act7_param;
+};
+
+constexpr int UF_TAP_BYTES = 8192;
+constexpr float UF_FIX = 262144.f;         // 2^18 fixed-point units per 1.0
+constexpr float UF_CLAMP = 900.f;          // |partial| clamp: 9 taps x 900 x 2^18 < 2^31 (a sane net is 100x below)
+
+template <int TH, int TW, int NW, int PT, int SLOTS>
+__global__ __launch_bounds__(NW * 64, 1) void upfuse_kernel(UpFuseParams p) {
+    constexpr int NTH = NW * 64;
+    constexpr int XR = TH + 4, XC = TW + 4;            // input halo tile (2-pixel ring)
+    constexpr int RH = TH + 1, RC = TW + 1;            // per sub-pixel: the up-conv pixels whose T values this tile needs
+    constexpr int NT = (RH * RC + 15) / 16;            // flattened 16-pixel MFMA tiles of that region
+    static_assert(NT <= NW * PT, "region does not fit the waves' pixel tiles");
+    constexpr int ROWP = XC;                           // LDS row pitch in pixels (the swizzle key depends on the column only)
+    constexpr int IN_BYTES = XR * ROWP * 128;
+    constexpr int OH = 2 * TH + 4, OW = 2 * TW + 4;    // accumulation image with a 2-pixel apron: no bounds checks on the adds
+    constexpr int OB_BYTES = OH * OW * 3 * 4;
+    constexpr int WAVE_BYTES = UF_TAP_BYTES / NW;
+    static_assert(WAVE_BYTES == 1024, "one LDS-DMA instruction per wave and tap");
+    constexpr int NCHUNK = 4;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[IN_BYTES + SLOTS * UF_TAP_BYTES + NCHUNK * 768 + OB_BYTES];
+    unsigned char* const wring = lds + IN_BYTES;
+    float* const par = (float*)(lds + IN_BYTES + SLOTS * UF_TAP_BYTES);
+    int* const obuf = (int*)(lds + IN_BYTES + SLOTS * UF_TAP_BYTES + NCHUNK * 768);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int pl = lane & 15, q = lane >> 4;
+
+    int b = blockIdx.x;
+    if ((gridDim.x & 7) == 0) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);      // XCD-aware tile order (see conv_c64_kernel)
+    const int tx = b % p.tiles_x; b /= p.tiles_x;
+    const int ty = b % p.tiles_y;
+    const int n = b / p.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    static_assert(IN_BYTES % 16 == 0 && (SLOTS * UF_TAP_BYTES) % 16 == 0, "16-byte aligned LDS regions");
+
+    // ---- weight stream of the up conv: one tap (8 KiB of A fragments) per ring slot, LDS-DMA (see conv_c64_kernel) ----
+    constexpr int ntap = NCHUNK * 9;
+    const unsigned char* wsrc = (const unsigned char*)p.w + wave * WAVE_BYTES + lane * 16;
+    const unsigned wring_lds = (unsigned)(uintptr_t)(lptr_t)wring;
+    auto issue_tap = [&](int g) {
+        const unsigned char* src = wsrc + (size_t)g * UF_TAP_BYTES;
+        const unsigned dst = __builtin_amdgcn_readfirstlane(wring_lds + (unsigned)((g % SLOTS) * UF_TAP_BYTES + wave * WAVE_BYTES));
+        unsigned keep;
+        asm volatile(
+            "s_mov_b32 %0, m0\n\t"
+            "s_mov_b32 m0, %2\n\t"
+            "s_nop 0\n\t"
+            "global_load_lds_dwordx4 %1, off\n\t"
+            "s_mov_b32 m0, %0"
+            : "=&s"(keep)
+            : "v"(src), "s"(dst)
+            : "memory");
+    };
+#pragma unroll
+    for (int g = 0; g < SLOTS - 1; ++g) issue_tap(g);
+
+    C64ParRegs pregs;
+    c64_params_load(pregs, p.epi, NCHUNK, tid);
+
+    // ---- last conv's weights as MFMA A fragments: row m = 3 * tap + oc of M-tile mt, K half ks.  thin_pack stores
+    // [tap][ks][lane = 16 * kgroup + row][8] with row = output channel, so the fragment of row (tap, oc) for this lane's
+    // k-group q is one 16-byte load.  Rows 27..31: zero.
+    bf16x8 w7f[2][2];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int m = 16 * mt + pl;
+        const int tap = m / 3, oc = m - 3 * tap;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            u32x4 v = {0u, 0u, 0u, 0u};
+            if (m < 27) v = *(const u32x4*)((const unsigned char*)p.w7 + ((size_t)((tap * 2 + ks) * 64 + q * 16 + oc)) * 16);
+            w7f[mt][ks] = __builtin_bit_cast(bf16x8, v);
+        }
+    }
+    // where this lane's 8 results (rows 16 mt + 4 q + e) go, relative to its T pixel, in ints of the accumulation image:
+    // tap (dy, dx) of T pixel (Y, X) belongs to output (Y - dy + 1, X - dx + 1), channel oc.  Rows >= 27 carry zeros.
+    int ooff[2][4];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int m = 16 * mt + 4 * q + e;
+            const int tap = m / 3, oc = m - 3 * tap;
+            const int dy = tap / 3, dx = tap - 3 * dy;
+            ooff[mt][e] = m < 27 ? ((1 - dy) * OW + (1 - dx)) * 3 + oc : 0;
+        }
+
+    // ---- stage the input halo tile (global NHWC bf16 -> registers -> swizzled LDS), zero the accumulation image ----
+    {
+        constexpr int NV = XR * XC * 8;                    // 16-byte pieces of the halo tile
+        constexpr int NB = (NV + NTH - 1) / NTH;
+        constexpr unsigned OOB = 0x80000000u;
+        const unsigned img_bytes = (unsigned)p.H * p.W * p.in_cs * 2;
+        const __amdgpu_buffer_rsrc_t xres = __builtin_amdgcn_make_buffer_rsrc(
+            (void*)(p.x + (size_t)n * p.H * p.W * p.in_cs), 0, img_bytes, 0x00020000);
+        const unsigned row_bytes = (unsigned)p.W * p.in_cs * 2;
+        u32x4 vb[NB];
+        unsigned lb[NB];
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int sidx = tid + i * NTH;
+            const int row = sidx / (XC * 8), rem = sidx - row * (XC * 8);
+            const int col = rem >> 3, chb = rem & 7;
+            const int gy = y0 - 2 + row, gx = x0 - 2 + col;
+            const bool ok = sidx < NV && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            const unsigned off = ok ? (unsigned)gy * row_bytes + (unsigned)gx * p.in_cs * 2 + chb * 16 : OOB;
+            vb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 0));
+            lb[i] = (row * ROWP + col) * 128 + ((chb ^ ((col >> 1) & 7)) << 4);
+        }
+        for (int i = tid; i < OB_BYTES / 16; i += NTH) ((u32x4*)obuf)[i] = (u32x4){0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            if (tid + i * NTH < NV) *(u32x4*)(lds + lb[i]) = vb[i];
+    }
+    static_assert(OB_BYTES % 16 == 0, "accumulation image is cleared in 16-byte pieces");
+
+    // ---- this wave's pixel tiles of the flattened (TH + 1) x (TW + 1) region.  Region pixel (ti, tj) of sub-pixel (si, sj)
+    // is up-conv pixel (y0 + ti - si, x0 + tj - sj); its 3x3 window starts at halo-tile pixel (ti + 1 - si, tj + 1 - sj),
+    // the swizzled LDS offsets of its three window columns are rebuilt per chunk. ----
+    int brow[PT], bcol[PT];
+    int obase[PT];            // ints: T pixel (2 ti, 2 tj) of this lane in the accumulation image (sub-pixel shift added per chunk)
+    unsigned live = 0;        // bit 8 s + k: the lane's pixel of tile k exists (not a clamped duplicate) and lies inside the image
+#pragma unroll
+    for (int k = 0; k < PT; ++k) {
+        const int flat = (wave * PT + k) * 16 + pl;
+        const int pix = min(flat, RH * RC - 1);
+        const int ti = pix / RC, tj = pix - ti * RC;
+#pragma unroll
+        for (int sq = 0; sq < 4; ++sq) {
+            const int gy = y0 + ti - (sq >> 1), gx = x0 + tj - (sq & 1);
+            live |= (flat < RH * RC && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? 1u << (8 * sq + k) : 0u;
+        }
+        obase[k] = ((2 * ti + 2) * OW + (2 * tj + 2)) * 3;
+        brow[k] = ti * (ROWP * 128);
+        bcol[k] = tj;
+    }
+    static_assert(PT <= 8, "live mask: 8 bits per sub-pixel");
+
+    c64_params_store(par, pregs, NCHUNK, tid);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    const int kind = c64_slope_kind(p.epi);
+
+#pragma unroll 1
+    for (int s = 0; s < NCHUNK; ++s) {
+        f32x4 acc[PT][4];
+#pragma unroll
+        for (int k = 0; k < PT; ++k)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) acc[k][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        const int si = s >> 1, sj = s & 1;
+        int boff[PT][3];
+#pragma unroll
+        for (int k = 0; k < PT; ++k)
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int col = bcol[k] + 1 - sj + dx;
+                boff[k][dx] = brow[k] + (1 - si) * (ROWP * 128) + col * 128 + ((q ^ ((col >> 1) & 7)) << 4);
+            }
+
+        bf16x8 afr[2][4], bfr[2][PT];
+        {
+            const unsigned char* wslot = wring + ((s * 9) % SLOTS) * UF_TAP_BYTES + lane * 16;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) afr[0][t] = *(const bf16x8*)(wslot + t * 1024);
+#pragma unroll
+            for (int k = 0; k < PT; ++k) bfr[0][k] = *(const bf16x8*)(lds + boff[k][0]);
+        }
+#pragma unroll
+        for (int j = 0; j < 18; ++j) {
+            const int tap = j >> 1, half = j & 1;
+            const int g = s * 9 + tap;
+            if (half == 1) {
+                if (g + 2 < ntap) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(SLOTS - 3) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                if (g + SLOTS - 1 < ntap) issue_tap(g + SLOTS - 1);
+            }
+            if (j + 1 < 18) {
+                const int tapn = (j + 1) >> 1, halfn = (j + 1) & 1;
+                const int dyn = tapn / 3, dxn = tapn - 3 * dyn;
+                const unsigned char* wslot = wring + ((s * 9 + tapn) % SLOTS) * UF_TAP_BYTES + lane * 16 + halfn * 4096;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) afr[(j + 1) & 1][t] = *(const bf16x8*)(wslot + t * 1024);
+#pragma unroll
+                for (int k = 0; k < PT; ++k)
+                    bfr[(j + 1) & 1][k] = *(const bf16x8*)(lds + ((boff[k][dxn] ^ (halfn << 6)) + dyn * (ROWP * 128)));
+            }
+#pragma unroll
+            for (int k = 0; k < PT; ++k)
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[j & 1][t], bfr[j & 1][k], acc[k][t], 0, 0, 0);
+            if (j + 1 < 18) sched_interleave<0, 4 + PT, 4 * PT>();
+        }
+
+        // ---- chunk s = sub-pixel (si, sj): T = bf16(act(acc * scale + shift)), then the last conv in scatter form ----
+        const float* par_s = par + s * 192;
+        f32x2 sc[8], sh[8], sl[8];
+#pragma unroll
+        for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+            for (int v4 = 0; v4 < 2; ++v4) {
+                const int c = 32 * hi + 8 * q + 4 * v4;
+                const f32x4 a = *(const f32x4*)(par_s + c);
+                const f32x4 bsh = *(const f32x4*)(par_s + 64 + c);
+                const f32x4 csl = *(const f32x4*)(par_s + 128 + c);
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    sc[4 * hi + 2 * v4 + e] = (f32x2){a[2 * e], a[2 * e + 1]};
+                    sh[4 * hi + 2 * v4 + e] = (f32x2){bsh[2 * e], bsh[2 * e + 1]};
+                    sl[4 * hi + 2 * v4 + e] = (f32x2){csl[2 * e], csl[2 * e + 1]};
+                }
+            }
+        const int sub = -(si * OW + sj) * 3;
+        const unsigned live_s = live >> (8 * s);
+        auto tail = [&](auto KIND) {
+#pragma unroll
+            for (int k = 0; k < PT; ++k) {
+                const unsigned keep = (unsigned)((int)(live_s << (31 - k)) >> 31);
+                u32x4 o0, o1;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        const int j = 2 * t + e;
+                        const f32x2 a = {acc[k][t][2 * e], acc[k][t][2 * e + 1]};
+                        f32x2 v;
+                        if constexpr (decltype(KIND)::value == 2) v = slope_act2(a, sc[j], sh[j], sl[j]);
+                        else if constexpr (decltype(KIND)::value == 1) v = slope_act2_max(a, sc[j], sh[j], sl[j]);
+                        else v = __builtin_elementwise_fma(a, sc[j], sh[j]);
+                        const unsigned w = pack_bf2(v[0], v[1]) & keep;        // T is zero outside the image (the last conv's padding)
+                        if (t < 2) o0[j & 3] = w; else o1[j & 3] = w;
+                    }
+                const bf16x8 b0 = __builtin_bit_cast(bf16x8, o0), b1 = __builtin_bit_cast(bf16x8, o1);
+                f32x4 d0 = {0.f, 0.f, 0.f, 0.f}, d1 = {0.f, 0.f, 0.f, 0.f};
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w7f[0][0], b0, d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w7f[1][0], b0, d1, 0, 0, 0);
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w7f[0][1], b1, d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w7f[1][1], b1, d1, 0, 0, 0);
+                int* const dst = obuf + obase[k] + sub;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float f0 = __builtin_amdgcn_fmed3f(d0[e], -UF_CLAMP, UF_CLAMP) * UF_FIX;
+                    const float f1 = __builtin_amdgcn_fmed3f(d1[e], -UF_CLAMP, UF_CLAMP) * UF_FIX;
+                    atomicAdd(dst + ooff[0][e], (int)__builtin_rintf(f0));
+                    if (16 + 4 * q + e < 27) atomicAdd(dst + ooff[1][e], (int)__builtin_rintf(f1));     // rows 27..31 do not exist
+                }
+            }
+        };
+        if (kind == 0) tail(std::integral_constant<int, 0>{});
+        else if (kind == 1) tail(std::integral_constant<int, 1>{});
+        else tail(std::integral_constant<int, 2>{});
+    }
+
+    // ---- all contributions are in: convert this tile's 2TH x 2TW x 3 outputs ----
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int Hout = 2 * p.H, Wout = 2 * p.W;
+    constexpr int PER = 2 * TH * 2 * TW;
+    for (int idx = tid; idx < 3 * PER; idx += NTH) {
+        const int oc = idx / PER;
+        const int rem = idx - oc * PER;
+        const int Yo = rem / (2 * TW), Xo = rem - Yo * (2 * TW);
+        const int Y = 2 * y0 + Yo, X = 2 * x0 + Xo;
+        if (Y < Hout && X < Wout) {
+            const float v = (float)obuf[((Yo + 2) * OW + Xo + 2) * 3 + oc] * (1.f / UF_FIX);
+            const float al = p.act7 == SRMI_ACT_PRELU ? p.alpha7[0] : 0.f;
+            p.y[(((size_t)n * 3 + oc) * Hout + Y) * Wout + X] = apply_act(v * p.scale7[oc] + p.shift7[oc], p.act7, p.act7_param, al);
+        }
+    }
+}
+
+// conv1: the c64 up conv (64 -> 256, PixelShuffle(2) in CRD order, dense bf16 NHWC output that ONLY conv2 reads);
+// conv2: the thin last conv (64 -> 3, NCHW f32 dense output, any pointwise activation, no residual).
+bool upfuse_supported(const srmi_conv_desc& d1, const srmi_conv_desc& d2) {
+    if (dbg_flags() & (1 << 13)) return false;                       // ablation / A-B switch: run the two launches
+    if (!c64_supported(d1) || !thin_supported(d2)) return false;
+    if (d1.Cout != 256 || d1.shuffle != 2 || d1.shuffle_order != SRMI_SHUFFLE_CRD) return false;
+    if ((d1.out_cstride && d1.out_cstride != 64) || d1.out_coffset) return false;
+    if (d1.act == SRMI_ACT_PRELU && d1.alpha_per_channel) return false;      // (per-channel slopes after the shuffle: not wired)
+    if (d2.Cout != 3 || d2.N != d1.N || d2.H != 2 * d1.H || d2.W != 2 * d1.W) return false;
+    if ((d2.in_cstride && d2.in_cstride != 64)) return false;
+    if (d2.out_layout != SRMI_NCHW || d2.out_dtype != SRMI_F32) return false;
+    if (d2.act == SRMI_ACT_PRELU && d2.alpha_per_channel) return false;
+    if (d1.H < 1 || d1.W < 1) return false;
+    return true;
+}
+
+int upfuse_launch(const srmi_conv_args& a1, const srmi_conv_args& a2, hipStream_t s) {
+    const srmi_conv_desc& d1 = a1.d;
+    const srmi_conv_desc& d2 = a2.d;
+    if (((uintptr_t)a1.x | (uintptr_t)a1.w | (uintptr_t)a2.w) & 15) {
+        set_error("upfuse_bf16: x and the weight buffers must be 16-byte aligned");
+        return SRMI_EINVAL;
+    }
+    if (a1.residual || a2.residual) { set_error("upfuse_bf16: residuals are not supported"); return SRMI_EUNSUPPORTED; }
+    UpFuseParams p;
+    p.x = (const bf16_t*)a1.x; p.w = (const bf16_t*)a1.w;
+    p.epi.scale = a1.scale; p.epi.shift = a1.shift; p.epi.alpha = a1.alpha; p.epi.res = nullptr; p.epi.y = nullptr;
+    p.epi.H = d1.H; p.epi.W = d1.W; p.epi.Cout = 256; p.epi.out_cs = 64; p.epi.out_co = 0; p.epi.mode = C64_CRD;
+    p.epi.act = d1.act; p.epi.act_param = d1.act_param; p.epi.alpha_pc = 0;
+    p.w7 = (const bf16_t*)a2.w; p.scale7 = a2.scale; p.shift7 = a2.shift; p.alpha7 = a2.alpha;
+    p.y = (float*)a2.y;
+    p.N = d1.N; p.H = d1.H; p.W = d1.W; p.in_cs = d1.in_cstride ? d1.in_cstride : 64;
+    p.act7 = d2.act; p.act7_param = d2.act_param;
+    if (d1.N == 0 || d1.H == 0 || d1.W == 0) return SRMI_OK;
+    p.tiles_x = (d1.W + 23) / 24; p.tiles_y = (d1.H + 23) / 24;
+    const long long nb = (long long)d1.N * p.tiles_x * p.tiles_y;
+    if (nb > 0x7fffffffLL) { set_error("upfuse_bf16: grid too large"); return SRMI_EINVAL; }
+    hipLaunchKernelGGL((upfuse_kernel<24, 24, 8, 5, 3>), dim3((unsigned)nb), dim3(512), 0, s, p);
+    return hip_check(hipGetLastError(), "upfuse_kernel");
+}
+
+}  // namespace srmi

@@ -133,8 +133,11 @@ class _Seq:
         lib = L.load()
         out, i = [], 0
         while i < n:
-            if (arr[i].flags & L.CONV_FUSE_NEXT) and i + 1 < n and lib.srmi_conv2d_can_fuse(C.byref(arr[i]), C.byref(arr[i + 1])):
-                out.append(("resblock_bf16", i, 2))
+            kind = 0
+            if (arr[i].flags & L.CONV_FUSE_NEXT) and i + 1 < n:
+                kind = lib.srmi_conv2d_can_fuse(C.byref(arr[i]), C.byref(arr[i + 1]))
+            if kind:
+                out.append(({1: "resblock_bf16", 2: "upfuse_bf16"}[kind], i, 2))
                 i += 2
             else:
                 out.append((kernels[i], i, 1))
@@ -167,12 +170,13 @@ class GeneratorPlan:
         feat = s.buf(N, H, W, nf)
         s.add(gen.conv02, cur, feat, N, H, W, residual=skip)      # P/srgan_model.py:33-34
         x, h, w = feat, H, W
-        for up in gen.tail:                        # Upsampler, P/ops.py:74-78
+        for j, up in enumerate(gen.tail):          # Upsampler, P/ops.py:74-78
             r = up.body[1].upscale_factor
             c2d = up.body[0].body[0]
             act = up.body[2] if len(up.body) > 2 else None
             y = s.buf(N, h * r, w * r, c2d.out_channels // (r * r))
-            s.add((c2d, None, act), x, y, N, h, w, shuffle=r)
+            # the last Upsampler and last_conv may run as ONE launch (its 4x-resolution output never reaches HBM)
+            s.add((c2d, None, act), x, y, N, h, w, shuffle=r, fuse_next=(j == len(gen.tail) - 1))
             x, h, w = y, h * r, w * r
         self.sr_shape = (N, img, h, w)
         sr0 = torch.empty(self.sr_shape, dtype=torch.float32, device=dev)   # placeholder; run() allocates fresh outputs

@@ -73,7 +73,8 @@ def test_generator_bf16_psnr(golden_dir, name):
     assert plan.kernels.count("c64_bf16") == 2 * int(g["num_block"]) + 3          # body + conv02 + 2 upsamplers
     labels = [l for l, _, _ in plan.launches]
     assert labels.count("resblock_bf16") == int(g["num_block"])                  # every ResBlock is ONE launch
-    assert labels[0] == "k9c3_bf16" and labels[-1] == "c64_thin_bf16"
+    # the second Upsampler and last_conv go out as ONE launch (the 4x-resolution tensor between them never reaches HBM)
+    assert labels[0] == "k9c3_bf16" and labels[-1] == "upfuse_bf16" and len(labels) == int(g["num_block"]) + 4
     sr = sr.cpu().numpy()
     # synthetic ground truth at the reference's logged operating point (26.48 dB)
     rng = np.random.Generator(np.random.PCG64(99))

@@ -342,6 +342,71 @@ def test_fused_resblock_kernel(case):
     assert L.load().srmi_resblock_fwd(C.byref(a1), C.byref(a2), Fn.stream_ptr()) == -2
 
 
+@pytest.mark.parametrize("case", [
+    dict(N=1, H=24, W=24),                        # exactly one tile
+    dict(N=1, H=48, W=72),                        # whole tiles only
+    dict(N=2, H=5, W=7),                          # smaller than a tile
+    dict(N=1, H=25, W=50),                        # ragged both ways, rings of neighbouring tiles overlap
+    dict(N=2, H=9, W=97, act2=L.ACT_NONE),        # no tanh: the raw fixed-point sums
+    dict(N=1, H=24, W=96, alpha=-0.75),           # slope outside [0, 1]: compare + select form
+    dict(N=1, H=16, W=49, alpha=1.0),
+    dict(N=1, H=1, W=1),
+    dict(N=3, H=2, W=200),
+])
+def test_fused_up_tail_kernel(case):
+    """conv3x3 64->256 -> PixelShuffle(2) -> PReLU -> conv3x3 64->3 -> tanh in one launch (srmi_conv2d_fwd_pair,
+    SRMI_FUSE_UPTAIL) against the CPU restatement and the two-launch path.  The intermediate T is the same bf16 tensor in
+    both paths (same MFMA order); the last conv differs by its int32 2^-18 fixed-point accumulation (nine adds:
+    <= 9 * 2^-19 = 1.7e-5 before the activation) and f32 summation order.  Two fused runs are bit-identical."""
+    import ctypes as C
+    lib = L.load()
+    g = _rng(11)
+    N, H, W = case["N"], case["H"], case["W"]
+    act2 = case.get("act2", L.ACT_TANH)
+    x = torch.from_numpy(g.uniform(-1, 1, (N, 64, H, W)).astype(np.float32)).bfloat16().float()
+    w1 = torch.from_numpy((g.standard_normal((256, 64, 3, 3)) / 24.0).astype(np.float32)).bfloat16().float()
+    w2 = torch.from_numpy((g.standard_normal((3, 64, 3, 3)) / 24.0).astype(np.float32)).bfloat16().float()
+    sc1 = torch.ones(256); sh1 = torch.from_numpy(g.uniform(-0.3, 0.3, 256).astype(np.float32))
+    sc2 = torch.ones(3); sh2 = torch.from_numpy(g.uniform(-0.3, 0.3, 3).astype(np.float32))
+    alpha = torch.tensor([case.get("alpha", 0.25)])
+    t_ref = _ref_fused(x, w1, sc1, sh1, L.ACT_PRELU, 0.0, alpha, None, 1, 1, 2, False).float().bfloat16().float()
+    ref = _ref_fused(t_ref, w2, sc2, sh2, act2, 0.0, None, None, 1, 1, 1, False)
+
+    d1 = Fn.make_desc(N, H, W, 64, 256, 3, in_dtype=L.BF16, out_dtype=L.BF16, compute=L.COMPUTE_BF16, act=L.ACT_PRELU, shuffle=2)
+    d2 = Fn.make_desc(N, 2 * H, 2 * W, 64, 3, 3, in_dtype=L.BF16, out_dtype=L.F32, out_layout=L.NCHW, compute=L.COMPUTE_BF16, act=act2)
+    assert L.kernel_name(d1) == "c64_bf16" and L.kernel_name(d2) == "c64_thin_bf16"
+    xd = x.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)
+    wp = [Fn.pack_weights(d1, w1.to(DEV)), Fn.pack_weights(d2, w2.to(DEV))]
+    dv = [t.to(DEV) for t in (sc1, sh1, sc2, sh2, alpha)]
+    tmp = torch.full((N, 2 * H, 2 * W, 64), 3.0, dtype=torch.bfloat16, device=DEV)
+    ys = [torch.full((N, 3, 2 * H, 2 * W), -5.0, dtype=torch.float32, device=DEV) for _ in range(2)]
+    a1, a2 = L.ConvArgs(), L.ConvArgs()
+    for y in ys:
+        Fn.fill_args(a1, d1, xd, wp[0], dv[0], dv[1], dv[4], None, tmp)
+        Fn.fill_args(a2, d2, tmp, wp[1], dv[2], dv[3], None, None, y)
+        a1.flags = L.CONV_FUSE_NEXT
+        assert lib.srmi_conv2d_can_fuse(C.byref(a1), C.byref(a2)) == 2
+        L.check(lib.srmi_conv2d_fwd_pair(C.byref(a1), C.byref(a2), Fn.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.all(tmp == 3.0)                      # the intermediate is never materialised
+    assert torch.equal(ys[0], ys[1])
+    got = ys[0].cpu()
+    err = (got.double() - ref).abs()
+    # vs the CPU restatement: a T element may round to the other bf16 neighbour (f32 vs f64 accumulation)
+    assert torch.all(err <= 2e-3), err.max().item()
+    # vs the two launches through the same ABI: same T bits, so only the last conv's accumulation differs
+    y2 = torch.empty_like(ys[0])
+    Fn.conv2d_fused(d1, xd, wp[0], dv[0], dv[1], dv[4], None, out=tmp)
+    Fn.conv2d_fused(d2, tmp, wp[1], dv[2], dv[3], None, None, out=y2)
+    torch.cuda.synchronize()
+    d = (ys[0] - y2).abs().max().item()
+    assert d <= 4e-5, d
+    # a residual on the last conv, or an output that aliases the input, is refused before any launch
+    Fn.fill_args(a2, d2, tmp, wp[1], dv[2], dv[3], None, ys[1], ys[0])
+    assert lib.srmi_conv2d_can_fuse(C.byref(a1), C.byref(a2)) == 0
+    assert lib.srmi_conv2d_fwd_pair(C.byref(a1), C.byref(a2), Fn.stream_ptr()) == -2
+
+
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_pool_and_upsample_addressing_ops(dtype):
     """srmi_maxpool2x2_nhwc (channel-slice input, floor sizes) and srmi_upsample2x_nhwc (store into a channel slice)."""
