@@ -41,6 +41,7 @@ struct UpFuseParams {
     int N, H, W, in_cs;                    // up conv geometry
     int tiles_x, tiles_y;
     int act7; float act7_param;
+    int vec4;                              // y 16-byte aligned and 2W % 4 == 0: whole-quad stores
 };
 
 constexpr int UF_TAP_BYTES = 8192;
@@ -292,7 +293,7 @@ __global__ __launch_bounds__(NW * 64, 1) void upfuse_kernel(UpFuseParams p) {
                     const float f0 = __builtin_amdgcn_fmed3f(d0[e], -UF_CLAMP, UF_CLAMP) * UF_FIX;
                     const float f1 = __builtin_amdgcn_fmed3f(d1[e], -UF_CLAMP, UF_CLAMP) * UF_FIX;
                     atomicAdd(dst + ooff[0][e], (int)__builtin_rintf(f0));
-                    if (16 + 4 * q + e < 27) atomicAdd(dst + ooff[1][e], (int)__builtin_rintf(f1));     // rows 27..31 do not exist
+                    atomicAdd(dst + ooff[1][e], (int)__builtin_rintf(f1));     // (rows 27..31: zero weights, adds 0 to the lane's own pixel)
                 }
             }
         };
@@ -301,20 +302,43 @@ __global__ __launch_bounds__(NW * 64, 1) void upfuse_kernel(UpFuseParams p) {
         else tail(std::integral_constant<int, 2>{});
     }
 
-    // ---- all contributions are in: convert this tile's 2TH x 2TW x 3 outputs ----
+    // ---- all contributions are in: convert this tile's 2TH x 2TW x 3 outputs.  One item = four consecutive columns of
+    // one (channel, row): three of them per thread and a bit, 16-byte stores when the image allows it ----
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     const int Hout = 2 * p.H, Wout = 2 * p.W;
-    constexpr int PER = 2 * TH * 2 * TW;
-    for (int idx = tid; idx < 3 * PER; idx += NTH) {
-        const int oc = idx / PER;
-        const int rem = idx - oc * PER;
-        const int Yo = rem / (2 * TW), Xo = rem - Yo * (2 * TW);
-        const int Y = 2 * y0 + Yo, X = 2 * x0 + Xo;
-        if (Y < Hout && X < Wout) {
-            const float v = (float)obuf[((Yo + 2) * OW + Xo + 2) * 3 + oc] * (1.f / UF_FIX);
-            const float al = p.act7 == SRMI_ACT_PRELU ? p.alpha7[0] : 0.f;
-            p.y[(((size_t)n * 3 + oc) * Hout + Y) * Wout + X] = apply_act(v * p.scale7[oc] + p.shift7[oc], p.act7, p.act7_param, al);
+    constexpr int CQ = 2 * TW / 4;                     // column quads per row
+    constexpr int NITEM = 3 * 2 * TH * CQ;
+    const float al7 = p.act7 == SRMI_ACT_PRELU ? p.alpha7[0] : 0.f;
+    const float s7[3] = {p.scale7[0] * (1.f / UF_FIX), p.scale7[1] * (1.f / UF_FIX), p.scale7[2] * (1.f / UF_FIX)};
+    const float h7[3] = {p.shift7[0], p.shift7[1], p.shift7[2]};
+    for (int item = tid; item < NITEM; item += NTH) {
+        const int ro = item / CQ, cq = item - ro * CQ;
+        const int oc = ro / (2 * TH), Yo = ro - oc * (2 * TH);
+        const int Y = 2 * y0 + Yo, X = 2 * x0 + 4 * cq;
+        if (Y >= Hout || X >= Wout) continue;
+        const float sc = oc == 0 ? s7[0] : oc == 1 ? s7[1] : s7[2];
+        const float sh = oc == 0 ? h7[0] : oc == 1 ? h7[1] : h7[2];
+        const int* src = obuf + ((Yo + 2) * OW + 4 * cq + 2) * 3 + oc;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float z = (float)src[3 * e] * sc + sh;
+            if (p.act7 == SRMI_ACT_TANH) {
+                // tanh z = sign(z) (1 - t) / (1 + t), t = exp(-2 |z|): hardware exp2 and rcp (1 ulp each), |error| < 3e-7
+                const float t = __builtin_amdgcn_exp2f(-2.885390082f * __builtin_fabsf(z));
+                v[e] = __builtin_copysignf((1.f - t) * __builtin_amdgcn_rcpf(1.f + t), z);
+            } else {
+                v[e] = apply_act(z, p.act7, p.act7_param, al7);
+            }
+        }
+        float* dst = p.y + (((size_t)n * 3 + oc) * Hout + Y) * Wout + X;
+        if (p.vec4 && X + 3 < Wout) {
+            *(f32x4*)dst = v;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (X + e < Wout) dst[e] = v[e];
         }
     }
 }
@@ -352,6 +376,7 @@ int upfuse_launch(const srmi_conv_args& a1, const srmi_conv_args& a2, hipStream_
     p.y = (float*)a2.y;
     p.N = d1.N; p.H = d1.H; p.W = d1.W; p.in_cs = d1.in_cstride ? d1.in_cstride : 64;
     p.act7 = d2.act; p.act7_param = d2.act_param;
+    p.vec4 = (((uintptr_t)a2.y & 15) == 0 && ((2 * d1.W) & 3) == 0) ? 1 : 0;
     if (d1.N == 0 || d1.H == 0 || d1.W == 0) return SRMI_OK;
     p.tiles_x = (d1.W + 23) / 24; p.tiles_y = (d1.H + 23) / 24;
     const long long nb = (long long)d1.N * p.tiles_x * p.tiles_y;

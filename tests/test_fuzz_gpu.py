@@ -57,6 +57,20 @@ def test_resblock_fuzz(case):
     K.test_fused_resblock_kernel(case)
 
 
+def _up_tail_cases(n, seed):
+    g = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        out.append(dict(N=int(g.integers(1, 4)), H=int(g.integers(1, 60)), W=int(g.integers(1, 110)),
+                        alpha=float(g.choice([0.25, 0.0, 1.0, -0.3])), act2=int(g.choice([L.ACT_TANH, L.ACT_NONE, L.ACT_SIGMOID]))))
+    return out
+
+
+@pytest.mark.parametrize("case", _up_tail_cases(12, seed=91))
+def test_up_tail_fuzz(case):
+    K.test_fused_up_tail_kernel(case)
+
+
 def _chain_cases(n, seed):
     g = np.random.default_rng(seed)
     out = []
