@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SRMI_VERSION 111 /* 0.1.1: dgrad / wgrad take a workspace (deterministic split-K), no float atomics left */
+#define SRMI_VERSION 112 /* 0.1.1: dgrad / wgrad take a workspace (deterministic split-K), no float atomics left */
 
 /* error codes */
 #define SRMI_OK 0
@@ -120,8 +120,20 @@ int srmi_version(void);
 /* message for the calling thread's most recent failure ("" if none). */
 const char* srmi_last_error(void);
 
-/* name of the kernel the dispatcher selects for `d` ("generic_f32", "c64_bf16", ...). */
+/* name of the kernel the dispatcher selects for `d`: "generic_f32", "c64_bf16", "cin_bf16", "c64_thin_bf16",
+ * "k9c3_bf16", "k9c1_bf16", "pw_bf16", "c1out_bf16". */
 int srmi_conv2d_kernel_name(const srmi_conv_desc* d, char* buf, size_t buf_len);
+
+/* The HBM-bound SRCNN layers (SRCNN/srcnn.py:205-210) by name: the same descriptors go through srmi_conv2d_fwd, these
+ * entry points only REFUSE (SRMI_EUNSUPPORTED) anything the dedicated kernel does not run, so a caller that asks for
+ * them never lands on the generic kernel silently.  Weights packed by srmi_conv2d_pack_weights for the same descriptor.
+ *   c1in : 9x9, ONE input channel (f32 plane) -> 64 g channels, NHWC bf16 out, none | ReLU | LeakyReLU | scalar PReLU
+ *          ("k9c1_bf16": the 81 taps packed on the MFMA K axis; 4 B in + 2 Cout B out per pixel).
+ *   c1out: k x k (3 | 5), 32 | 64 channels (NHWC bf16) -> ONE channel, f32 | bf16 out, any pointwise activation
+ *          ("c1out_bf16": banded MFMA operand, every input row streamed once, no atomics; 2 Cin B in + 4 B out per pixel).
+ * The 1x1 middle layer of the 9-1-5 variant is "pw_bf16" (Cin 32|64|128 -> Cout 16|32|64, streaming bf16 GEMM). */
+int srmi_srcnn_layer_c1in(const srmi_conv_args* a, void* stream);
+int srmi_srcnn_layer_c1out(const srmi_conv_args* a, void* stream);
 
 /* bytes of the kernel-native packed weight buffer for `d`. */
 int srmi_conv2d_packed_weight_bytes(const srmi_conv_desc* d, size_t* bytes);

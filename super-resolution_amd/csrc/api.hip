@@ -133,7 +133,10 @@ int select_kernel(const srmi_conv_desc& d) {
     if (c64_supported(d)) return K_C64_BF16;
     if (cin_supported(d)) return K_CIN_BF16;
     if (thin_supported(d)) return K_THIN_BF16;
+    if (k9c1_supported(d)) return K_K9C1_BF16;
     if (k9c3_supported(d)) return K_K9C3_BF16;
+    if (pw_supported(d)) return K_PW_BF16;
+    if (c1_supported(d)) return K_C1OUT_BF16;
     return K_GENERIC_F32;
 }
 
@@ -143,6 +146,9 @@ const char* kernel_label(int k) {
         case K_THIN_BF16: return "c64_thin_bf16";
         case K_K9C3_BF16: return "k9c3_bf16";
         case K_CIN_BF16: return "cin_bf16";
+        case K_PW_BF16: return "pw_bf16";
+        case K_K9C1_BF16: return "k9c1_bf16";
+        case K_C1OUT_BF16: return "c1out_bf16";
         default: return "generic_f32";
     }
 }
@@ -170,6 +176,9 @@ static int conv_fwd_one(const srmi_conv_args* a, hipStream_t s, void* ws = nullp
         case K_THIN_BF16: return thin_launch(*a, g, s);   // rejects a residual (SRMI_EUNSUPPORTED)
         case K_K9C3_BF16: return k9c3_launch(*a, g, s);
         case K_CIN_BF16: return cin_launch(*a, g, s);
+        case K_PW_BF16: return pw_launch(*a, g, s);
+        case K_K9C1_BF16: return k9c1_launch(*a, g, s);
+        case K_C1OUT_BF16: return c1_launch(*a, g, s);
         default: return generic_launch(*a, g, s, ws, ws_bytes);
     }
 }
@@ -203,6 +212,9 @@ int srmi_conv2d_packed_weight_bytes(const srmi_conv_desc* d, size_t* bytes) {
         case K_THIN_BF16: *bytes = thin_packed_bytes(*d); break;
         case K_K9C3_BF16: *bytes = k9c3_packed_bytes(*d); break;
         case K_CIN_BF16: *bytes = cin_packed_bytes(*d); break;
+        case K_PW_BF16: *bytes = pw_packed_bytes(*d); break;
+        case K_K9C1_BF16: *bytes = k9c1_packed_bytes(*d); break;
+        case K_C1OUT_BF16: *bytes = c1_packed_bytes(*d); break;
         default: *bytes = generic_packed_bytes(*d);
     }
     return SRMI_OK;
@@ -219,11 +231,29 @@ int srmi_conv2d_pack_weights(const srmi_conv_desc* d, const float* w_oihw, void*
         case K_THIN_BF16: return thin_pack(*d, w_oihw, w_packed, s);
         case K_K9C3_BF16: return k9c3_pack(*d, w_oihw, w_packed, s);
         case K_CIN_BF16: return cin_pack(*d, w_oihw, w_packed, s);
+        case K_PW_BF16: return pw_pack(*d, w_oihw, w_packed, s);
+        case K_K9C1_BF16: return k9c1_pack(*d, w_oihw, w_packed, s);
+        case K_C1OUT_BF16: return c1_pack(*d, w_oihw, w_packed, s);
         default: return generic_pack(*d, w_oihw, w_packed, s);
     }
 }
 
 int srmi_conv2d_fwd(const srmi_conv_args* a, void* stream) { return conv_fwd_one(a, (hipStream_t)stream); }
+
+static int srcnn_layer(const srmi_conv_args* a, void* stream, int kernel, const char* what) {
+    if (!a) { set_error("%s: NULL args", what); return SRMI_EINVAL; }
+    ConvGeom g;
+    int rc = conv_geom(a->d, &g);
+    if (rc) return rc;
+    if (select_kernel(a->d) != kernel) {
+        set_error("%s: not this kernel's shape (the dispatcher picks %s)", what, kernel_label(select_kernel(a->d)));
+        return SRMI_EUNSUPPORTED;
+    }
+    return conv_fwd_one(a, (hipStream_t)stream);
+}
+
+int srmi_srcnn_layer_c1in(const srmi_conv_args* a, void* stream) { return srcnn_layer(a, stream, K_K9C1_BF16, "srcnn_layer_c1in"); }
+int srmi_srcnn_layer_c1out(const srmi_conv_args* a, void* stream) { return srcnn_layer(a, stream, K_C1OUT_BF16, "srcnn_layer_c1out"); }
 
 int srmi_conv2d_workspace_bytes(const srmi_conv_desc* d, size_t* bytes) {
     if (!d || !bytes) { set_error("workspace_bytes: NULL argument"); return SRMI_EINVAL; }

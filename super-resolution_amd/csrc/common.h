@@ -75,7 +75,7 @@ int dbg_flags();
 int dbg_thin_rows();
 
 // kernel families (dispatch.cpp decides, the .hip files implement)
-enum Kernel { K_GENERIC_F32 = 0, K_C64_BF16 = 1, K_THIN_BF16 = 2, K_K9C3_BF16 = 3, K_CIN_BF16 = 4 };
+enum Kernel { K_GENERIC_F32 = 0, K_C64_BF16 = 1, K_THIN_BF16 = 2, K_K9C3_BF16 = 3, K_CIN_BF16 = 4, K_PW_BF16 = 5, K_C1OUT_BF16 = 6, K_K9C1_BF16 = 7 };
 const char* kernel_label(int k);
 int select_kernel(const srmi_conv_desc& d);
 
@@ -108,6 +108,22 @@ bool cin_supported(const srmi_conv_desc& d);
 size_t cin_packed_bytes(const srmi_conv_desc& d);
 int cin_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s);
 int cin_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s);
+
+// 9x9 conv of a one-channel image, taps packed on the K axis (conv_k9c1_bf16.hip): SRCNN's first layer
+bool k9c1_supported(const srmi_conv_desc& d);
+size_t k9c1_packed_bytes(const srmi_conv_desc& d);
+int k9c1_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s);
+int k9c1_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s);
+
+// HBM-bound SRCNN layer shapes (conv_srcnn_bf16.hip): 1x1 conv as a streaming bf16 GEMM; k x k conv to ONE channel
+bool pw_supported(const srmi_conv_desc& d);
+size_t pw_packed_bytes(const srmi_conv_desc& d);
+int pw_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s);
+int pw_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s);
+bool c1_supported(const srmi_conv_desc& d);
+size_t c1_packed_bytes(const srmi_conv_desc& d);
+int c1_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s);
+int c1_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s);
 
 // fused ResBlock (conv_resblock_bf16.hip)
 bool resblock_supported(const srmi_conv_desc& d1, const srmi_conv_desc& d2);

@@ -92,6 +92,8 @@ SYMBOLS = {
     "srmi_chain_enable": (C.c_int, [C.c_int32]),
     "srmi_conv2d_can_fuse": (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs)]),
     "srmi_conv2d_fwd_pair": (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), C.c_void_p]),
+    "srmi_srcnn_layer_c1in": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
+    "srmi_srcnn_layer_c1out": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "srmi_resblock_fwd": (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), C.c_void_p]),
     "srmi_layout_convert": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                       C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

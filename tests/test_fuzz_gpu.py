@@ -87,6 +87,44 @@ def test_chain_fuzz(case):
     Cg.test_chain_matches_per_block_launches(case)
 
 
+def _srcnn_cases(n, seed):
+    g = np.random.default_rng(seed)
+    pw, c1, k9 = [], [], []
+    for i in range(n):
+        Cin, Cout = int(g.choice([32, 64, 128])), int(g.choice([16, 32, 64]))
+        case = dict(N=int(g.integers(1, 4)), H=int(g.integers(1, 40)), W=int(g.integers(1, 90)), Cin=Cin, Cout=Cout,
+                    act=int(g.choice([L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU, L.ACT_PRELU])), act_param=0.2)
+        if i % 3 == 0:
+            case.update(in_cs=Cin + 8 * int(g.integers(1, 5)), out_cs=Cout + 32, out_co=4 * int(g.integers(0, 9)))
+        if i % 4 == 1:
+            case.update(residual=True)
+        pw.append(case)
+        c1.append(dict(N=int(g.integers(1, 3)), H=int(g.integers(1, 50)), W=int(g.integers(1, 420)), Cin=int(g.choice([32, 64])),
+                       k=int(g.choice([3, 5])), act=int(g.choice([L.ACT_NONE, L.ACT_RELU, L.ACT_TANH])),
+                       in_cs=0 if i % 3 else 72, out_bf16=bool(i % 5 == 4)))
+        k9.append(dict(N=int(g.integers(1, 3)), H=int(g.integers(1, 50)), W=int(g.integers(1, 200)), Cout=int(g.choice([64, 128])),
+                       act=int(g.choice([L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU, L.ACT_PRELU]))))
+    return pw, c1, k9
+
+
+_PW, _C1, _K9 = _srcnn_cases(10, seed=404)
+
+
+@pytest.mark.parametrize("case", _PW)
+def test_pw_fuzz(case):
+    K.test_pw_bf16_kernel(case)
+
+
+@pytest.mark.parametrize("case", _C1)
+def test_c1out_fuzz(case):
+    K.test_c1out_bf16_kernel(case)
+
+
+@pytest.mark.parametrize("case", _K9)
+def test_k9c1_fuzz(case):
+    K.test_k9c1_kernel(case)
+
+
 def _cin_cases(n, seed):
     g = np.random.default_rng(seed)
     out = []

@@ -217,6 +217,63 @@ def test_cin_bf16_kernel(case):
 
 
 @pytest.mark.parametrize("case", [
+    dict(N=2, H=9, W=13, Cin=64, Cout=32, act=L.ACT_RELU),                     # BASELINE config 2's middle layer (9-1-5)
+    dict(N=1, H=4, W=4, Cin=32, Cout=16, act=L.ACT_NONE),                      # one pixel tile exactly
+    dict(N=3, H=31, W=67, Cin=128, Cout=64, act=L.ACT_LRELU, act_param=0.2),   # many tiles, the 2-tiles-in-flight variant
+    dict(N=1, H=5, W=7, Cin=64, Cout=64, act=L.ACT_PRELU, alpha_pc=1),
+    dict(N=1, H=8, W=9, Cin=32, Cout=32, act=L.ACT_PRELU, in_cs=48, out_cs=64, out_co=16),   # channel slices both sides
+    dict(N=2, H=6, W=5, Cin=128, Cout=16, act=L.ACT_RELU),
+    dict(N=2, H=7, W=9, Cin=64, Cout=64, act=L.ACT_NONE, residual=True),                 # 1x1 skip projection + add
+    dict(N=1, H=7, W=9, Cin=32, Cout=32, act=L.ACT_RELU, residual=True, res_cs=48),
+])
+def test_pw_bf16_kernel(case):
+    """1x1 conv as a streaming bf16 MFMA GEMM (SRCNN-style 1x1 middle layer): one output rounding."""
+    assert _run_case(k=1, io=torch.bfloat16, compute=L.COMPUTE_BF16, **case) == "pw_bf16"
+
+
+@pytest.mark.parametrize("case", [
+    dict(N=2, H=11, W=30, Cin=32, k=5, act=L.ACT_NONE),                        # BASELINE config 2's last layer (9-1-5)
+    dict(N=1, H=40, W=200, Cin=64, k=5, act=L.ACT_NONE),                       # SRCNN/srcnn.py:209-210; 2 strips, several bands
+    dict(N=1, H=1, W=1, Cin=32, k=5, act=L.ACT_TANH),
+    dict(N=2, H=9, W=193, Cin=32, k=5, act=L.ACT_SIGMOID),                     # one column into the second strip
+    dict(N=1, H=17, W=29, Cin=32, k=3, act=L.ACT_RELU),                        # 14 outputs per block: scalar stores
+    dict(N=1, H=8, W=230, Cin=64, k=5, act=L.ACT_NONE, in_cs=96),              # channel-slice input
+    dict(N=1, H=12, W=36, Cin=32, k=5, act=L.ACT_NONE, out_bf16=True),
+])
+def test_c1out_bf16_kernel(case):
+    """k x k conv to ONE channel (banded MFMA operand, rows streamed once): bf16 in, f32 (or bf16) out, f32 sums of
+    exact bf16 products - summation-order error only."""
+    g = _rng(13)
+    N, H, W, Cin, k = case["N"], case["H"], case["W"], case["Cin"], case["k"]
+    act, in_cs = case["act"], case.get("in_cs", 0)
+    obf = case.get("out_bf16", False)
+    x = torch.from_numpy(g.uniform(-1, 1, (N, Cin, H, W)).astype(np.float32)).bfloat16().float()
+    w = torch.from_numpy((g.standard_normal((1, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)).bfloat16().float()
+    scale = torch.from_numpy(g.uniform(0.5, 1.5, 1).astype(np.float32))
+    shift = torch.from_numpy(g.uniform(-0.3, 0.3, 1).astype(np.float32))
+    ref = _ref_fused(x, w, scale, shift, act, 0.0, None, None, 1, k // 2, 1, False)
+    desc = Fn.make_desc(N, H, W, Cin, 1, k, in_dtype=L.BF16, out_dtype=L.BF16 if obf else L.F32, out_layout=L.NCHW,
+                        compute=L.COMPUTE_BF16, act=act, in_cstride=in_cs)
+    # (3x3 from 64 channels is the older c64_thin kernel's shape: it keeps it)
+    assert L.kernel_name(desc) == ("c64_thin_bf16" if (k, Cin) == (3, 64) else "c1out_bf16")
+    xd = torch.full((N, H, W, in_cs or Cin), 7.0, dtype=torch.bfloat16)
+    xd[..., :Cin] = x.permute(0, 2, 3, 1).bfloat16()
+    wp = Fn.pack_weights(desc, w.to(DEV))
+    y = Fn.conv2d_fused(desc, xd.to(DEV), wp, scale.to(DEV), shift.to(DEV))
+    if (k, Cin) != (3, 64):
+        import ctypes as C
+        y2 = torch.empty_like(y)
+        a, dv = L.ConvArgs(), [t.to(DEV) for t in (xd, scale, shift)]
+        Fn.fill_args(a, desc, dv[0], wp, dv[1], dv[2], None, None, y2)
+        L.check(L.load().srmi_srcnn_layer_c1out(C.byref(a), Fn.stream_ptr()))  # the by-name entry point: same launch
+        assert torch.equal(y, y2)
+    torch.cuda.synchronize()
+    err = (y.float().cpu().double() - ref).abs()
+    tol = 2.0 ** -8 * (ref.abs() + 1.0) if obf else torch.full_like(ref, 2e-5)
+    assert torch.all(err <= tol), err.max().item()
+
+
+@pytest.mark.parametrize("case", [
     dict(N=2, H=10, W=12, Cout=3, act=L.ACT_TANH, out_layout=L.NCHW),          # last_conv (ragged tile)
     dict(N=1, H=6, W=64, Cout=3, act=L.ACT_TANH, out_layout=L.NCHW),           # exactly one tile
     dict(N=1, H=13, W=130, Cout=3, act=L.ACT_TANH, out_layout=L.NCHW),         # several tiles, ragged both ways
@@ -252,7 +309,7 @@ def test_c64_thin_kernel(case):
     dict(N=1, H=13, W=100, in_layout=L.NCHW),               # big tile, ragged
     dict(N=2, H=6, W=96, in_layout=L.NCHW),                 # exactly one big tile per image
     dict(N=1, H=20, W=33, in_layout=L.NHWC),                # NHWC f32 input
-    dict(N=1, H=8, W=40, in_layout=L.NHWC, Cin=1),          # single-channel input (Y only)
+    dict(N=1, H=8, W=40, in_layout=L.NHWC, Cin=1, alpha_pc=1),          # single-channel input (Y only), per-channel slopes
     dict(N=1, H=10, W=70, in_layout=L.NCHW, Cin=1, Cout=128, alpha_pc=1),   # SRCNN conv1 (SRCNN/srcnn.py:203): two 64-ch launches
 ])
 def test_k9c3_kernel(case):
@@ -269,7 +326,8 @@ def test_k9c3_kernel(case):
     ref = _ref_fused(x.bfloat16().float(), w.bfloat16().float(), scale, shift, L.ACT_PRELU, 0.0, alpha, None, 1, 4, 1, False)
     desc = Fn.make_desc(N, H, W, Cin, Cout, 9, in_dtype=L.F32, out_dtype=L.BF16, in_layout=case["in_layout"],
                         compute=L.COMPUTE_BF16, act=L.ACT_PRELU, alpha_per_channel=apc)
-    assert L.kernel_name(desc) == "k9c3_bf16"
+    # (one input channel with a scalar slope is the dense-tap kernel's shape)
+    assert L.kernel_name(desc) == ("k9c1_bf16" if Cin == 1 and not apc else "k9c3_bf16")
     xd = (x if case["in_layout"] == L.NCHW else x.permute(0, 2, 3, 1).contiguous()).to(DEV)
     wp = Fn.pack_weights(desc, w.to(DEV))
     y = Fn.conv2d_fused(desc, xd, wp, scale.to(DEV), shift.to(DEV), alpha.to(DEV))
@@ -277,6 +335,47 @@ def test_k9c3_kernel(case):
     got = y.float().cpu().permute(0, 3, 1, 2)
     err = (got.double() - ref).abs()
     assert torch.all(err <= 2.0 ** -8 * (ref.abs() + 1.0)), err.max().item()
+
+
+@pytest.mark.parametrize("case", [
+    dict(N=2, H=9, W=7, Cout=64, act=L.ACT_RELU),                          # smaller than the window reach
+    dict(N=1, H=16, W=64, Cout=64, act=L.ACT_RELU),                        # exactly one tile
+    dict(N=1, H=37, W=150, Cout=128, act=L.ACT_RELU),                      # SRCNN/srcnn.py:205: two channel groups, ragged
+    dict(N=2, H=17, W=65, Cout=64, act=L.ACT_PRELU, in_layout=L.NHWC),     # scalar PReLU, NHWC spelling of the same plane
+    dict(N=1, H=5, W=130, Cout=64, act=L.ACT_NONE, out_cs=96, out_co=32),  # store into a channel slice
+    dict(N=1, H=20, W=20, Cout=192, act=L.ACT_LRELU),
+])
+def test_k9c1_kernel(case):
+    """9x9 conv of a one-channel image (SRCNN's first layer): 81 taps packed densely on the MFMA K axis, f32 in ->
+    NHWC bf16 out; x and w are rounded to bf16 before the MFMA, so is the reference."""
+    g = _rng(14)
+    N, H, W, Cout, act = case["N"], case["H"], case["W"], case["Cout"], case["act"]
+    out_cs, out_co = case.get("out_cs", 0), case.get("out_co", 0)
+    x = torch.from_numpy(g.uniform(-1, 1, (N, 1, H, W)).astype(np.float32))
+    w = torch.from_numpy((g.standard_normal((Cout, 1, 9, 9)) / 9.0).astype(np.float32))
+    scale = torch.from_numpy(g.uniform(0.5, 1.5, Cout).astype(np.float32))
+    shift = torch.from_numpy(g.uniform(-0.3, 0.3, Cout).astype(np.float32))
+    alpha = torch.tensor([0.25])
+    ref = _ref_fused(x.bfloat16().float(), w.bfloat16().float(), scale, shift, act, 0.1, alpha, None, 1, 4, 1, False)
+    desc = Fn.make_desc(N, H, W, 1, Cout, 9, in_dtype=L.F32, out_dtype=L.BF16, in_layout=case.get("in_layout", L.NCHW),
+                        compute=L.COMPUTE_BF16, act=act, act_param=0.1, out_cstride=out_cs, out_coffset=out_co)
+    assert L.kernel_name(desc) == "k9c1_bf16"
+    wp = Fn.pack_weights(desc, w.to(DEV))
+    yd = torch.full((N, H, W, out_cs or Cout), -5.0, dtype=torch.bfloat16, device=DEV)
+    import ctypes as C
+    a, dv = L.ConvArgs(), [t.to(DEV) for t in (x, scale, shift, alpha)]
+    Fn.fill_args(a, desc, dv[0], wp, dv[1], dv[2], dv[3], None, yd)
+    L.check(L.load().srmi_srcnn_layer_c1in(C.byref(a), Fn.stream_ptr()))       # the by-name entry point (SURVEY 8 b2)
+    assert L.load().srmi_srcnn_layer_c1out(C.byref(a), Fn.stream_ptr()) == -2   # ... which refuses other shapes
+    torch.cuda.synchronize()
+    y = yd.float().cpu()
+    got = y[..., out_co:out_co + Cout].permute(0, 3, 1, 2)
+    err = (got.double() - ref).abs()
+    assert torch.all(err <= 2.0 ** -8 * (ref.abs() + 1.0)), err.max().item()
+    if out_cs:
+        mask = torch.ones(out_cs, dtype=torch.bool)
+        mask[out_co:out_co + Cout] = False
+        assert torch.all(y[..., mask] == -5.0)
 
 
 @pytest.mark.parametrize("case", [

@@ -15,7 +15,7 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "super-resolution_amd")]
 import torch
 
 
-def run(name, model, x, out_px, flop_per_step, steps, warmup, compute):
+def run(name, model, x, out_px, flop_per_step, steps, warmup, compute, per_layer=False):
     model = model.to("cuda:0").eval().set_compute(compute)
     x = x.to("cuda:0")
     with torch.no_grad():
@@ -28,9 +28,50 @@ def run(name, model, x, out_px, flop_per_step, steps, warmup, compute):
         torch.cuda.synchronize()
         el = (time.perf_counter() - t0) / steps
     plan = model._plans.get(model, x.shape[0], x.shape[2], x.shape[3], 1 if compute == "bf16" else 0)
-    print(json.dumps({"workload": name, "compute": compute, "ms_per_step": round(el * 1e3, 3),
-                      "out_mp_per_s": round(out_px / 1e6 / el, 1), "tflops": round(flop_per_step / el / 1e12, 1),
-                      "kernels": dict(collections.Counter(plan.kernels))}), flush=True)
+    rec = {"workload": name, "compute": compute, "ms_per_step": round(el * 1e3, 3),
+           "out_mp_per_s": round(out_px / 1e6 / el, 1), "tflops": round(flop_per_step / el / 1e12, 1),
+           "kernels": dict(collections.Counter(plan.kernels))}
+    if per_layer:
+        rec["layers"] = layer_table(plan, x)
+        # the whole net against its compulsory traffic (input + output only: what ONE fused launch would move)
+        io = x.numel() * 4 + out_px * 4
+        rec["hbm_frac_compulsory"] = round(io / el / HBM_PEAK, 4)
+        rec["hbm_frac_layerwise"] = round(sum(v["algorithmic_bytes"] for v in rec["layers"].values()) / el / HBM_PEAK, 4)
+    print(json.dumps(rec), flush=True)
+
+
+HBM_PEAK = 8e12     # B/s, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def layer_table(plan, x, reps=10):
+    """Per-launch HIP-event time of a conv plan and its achieved HBM rate on the layer's own algorithmic bytes
+    (input tensor + output tensor, each once)."""
+    import ctypes as C
+    from srmi import _lib as L
+    from srmi import functional as Fn
+    lib, st = L.load(), Fn.stream_ptr()
+    plan.args[0].x = x.data_ptr()
+    esz = {L.F32: 4, L.BF16: 2}
+    tot = [0.0] * plan.n
+    for _ in range(reps):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(plan.n + 1)]
+        ev[0].record()
+        for i in range(plan.n):
+            L.check(lib.srmi_conv2d_fwd(C.byref(plan.args[i]), st))
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        for i in range(plan.n):
+            tot[i] += ev[i].elapsed_time(ev[i + 1]) * 1e-3 / reps
+    out = {}
+    for i in range(plan.n):
+        d = plan.args[i].d
+        px = d.N * d.H * d.W
+        nbytes = px * (d.Cin * esz[d.in_dtype] + d.Cout * esz[d.out_dtype])
+        flops = 2.0 * px * d.Cin * d.Cout * d.kh * d.kw
+        out[f"{i}:{plan.kernels[i]}:{d.Cin}->{d.Cout}k{d.kh}"] = {
+            "us": round(tot[i] * 1e6, 1), "algorithmic_bytes": nbytes, "GB/s": round(nbytes / tot[i] / 1e9, 1),
+            "frac_of_8TB/s": round(nbytes / tot[i] / HBM_PEAK, 4), "tflops": round(flops / tot[i] / 1e12, 1)}
+    return out
 
 
 def main():
@@ -39,38 +80,44 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--compute", default="bf16")
     ap.add_argument("--blocks", type=int, default=23)
+    ap.add_argument("--only", default="", help="comma list of cfg2,cfg5,cfg4 (default: all)")
     args = ap.parse_args()
+    only = set(filter(None, args.only.split(",")))
     from srmi.keras_models import SRCNN, RRDBNet
     g = torch.Generator().manual_seed(0)
-    x2 = torch.rand(32, 1, 384, 384, generator=g)
-    px2 = 32 * 384 * 384
-    run("cfg2 SRCNN 9-3-5 128/64 (reference), 32x1x384x384", SRCNN(), x2, px2, px2 * 171_392.0, args.steps, args.warmup, args.compute)
-    run("cfg2 SRCNN 9-1-5 64/32 (BASELINE), 32x1x384x384", SRCNN(k=(9, 1, 5), ch=(64, 32)), x2, px2, px2 * 16_064.0,
-        args.steps, args.warmup, args.compute)
-    # cfg5: one 960x540 frame -> 3840x2160 through LR tiles of 270x240 + 8 px halo (8 tiles, here all on one GPU)
-    from srmi.srgan_model import Generator
-    from srmi.tiling import sr_tiled
-    from bench import synthetic_state
-    gen = Generator()
-    gen.load_state_dict(synthetic_state(gen, 0))
-    gen = gen.to("cuda:0").eval().set_compute(args.compute)
-    frame = (torch.rand(1, 3, 540, 960, generator=g) * 2 - 1).to("cuda:0")
-    with torch.no_grad():
-        for _ in range(args.warmup):
-            sr_tiled(gen, frame, tile=(270, 240), halo=8)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out, ntiles = sr_tiled(gen, frame, tile=(270, 240), halo=8)
-        torch.cuda.synchronize()
-        el = (time.perf_counter() - t0) / args.steps
-    print(json.dumps({"workload": "cfg5 SRResNet x4, 960x540 -> 3840x2160, 8 tiles of 270x240 + 8 px halo, 1 GPU",
-                      "compute": args.compute, "ms_per_frame": round(el * 1e3, 3), "out_mp_per_s": round(8.2944 / el, 1),
-                      "tiles": ntiles}), flush=True)
-    x4 = torch.rand(8, 3, 256, 256, generator=g) * 2 - 1
-    lr_px = 8 * 256 * 256
-    run(f"cfg4 RRDBNet {args.blocks} blocks, 8x3x256x256 -> x4", RRDBNet(num_blocks=args.blocks), x4, lr_px * 16,
-        lr_px * 2.0 * (175_104 * args.blocks + 803_520), args.steps, args.warmup, args.compute)
+    if not only or "cfg2" in only:
+        x2 = torch.rand(32, 1, 384, 384, generator=g)
+        px2 = 32 * 384 * 384
+        run("cfg2 SRCNN 9-3-5 128/64 (reference), 32x1x384x384", SRCNN(), x2, px2, px2 * 171_392.0, args.steps,
+            args.warmup, args.compute, per_layer=True)
+        run("cfg2 SRCNN 9-1-5 64/32 (BASELINE), 32x1x384x384", SRCNN(k=(9, 1, 5), ch=(64, 32)), x2, px2, px2 * 16_064.0,
+            args.steps, args.warmup, args.compute, per_layer=True)
+    if not only or "cfg5" in only:
+        # cfg5: one 960x540 frame -> 3840x2160 through LR tiles of 270x240 + 8 px halo (8 tiles, here all on one GPU)
+        from srmi.srgan_model import Generator
+        from srmi.tiling import sr_tiled
+        from bench import synthetic_state
+        gen = Generator()
+        gen.load_state_dict(synthetic_state(gen, 0))
+        gen = gen.to("cuda:0").eval().set_compute(args.compute)
+        frame = (torch.rand(1, 3, 540, 960, generator=g) * 2 - 1).to("cuda:0")
+        with torch.no_grad():
+            for _ in range(args.warmup):
+                sr_tiled(gen, frame, tile=(270, 240), halo=8)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                out, ntiles = sr_tiled(gen, frame, tile=(270, 240), halo=8)
+            torch.cuda.synchronize()
+            el = (time.perf_counter() - t0) / args.steps
+        print(json.dumps({"workload": "cfg5 SRResNet x4, 960x540 -> 3840x2160, 8 tiles of 270x240 + 8 px halo, 1 GPU",
+                          "compute": args.compute, "ms_per_frame": round(el * 1e3, 3), "out_mp_per_s": round(8.2944 / el, 1),
+                          "tiles": ntiles}), flush=True)
+    if not only or "cfg4" in only:
+        x4 = torch.rand(8, 3, 256, 256, generator=g) * 2 - 1
+        lr_px = 8 * 256 * 256
+        run(f"cfg4 RRDBNet {args.blocks} blocks, 8x3x256x256 -> x4", RRDBNet(num_blocks=args.blocks), x4, lr_px * 16,
+            lr_px * 2.0 * (175_104 * args.blocks + 803_520), args.steps, args.warmup, args.compute)
 
 
 if __name__ == "__main__":
