@@ -8,7 +8,7 @@ PixelShuffle) forward, batch 16x3x96x96 LR, random init", the configuration nort
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A step = one `Generator.forward(lr) -> (sr, feat)` through the drop-in module surface (NCHW f32 in
-HBM -> NCHW f32 out), i.e. 37 convs in 21 launches (ResBlocks fused) + 1 re-layout of `feat`.  Inference shards by batch
+HBM -> NCHW f32 out), i.e. 37 convs in 20 launches (ResBlocks fused, second Upsampler + last_conv fused) + 1 re-layout of `feat`.  Inference shards by batch
 item with no collective: every rank runs the same per-GPU batch (weak scaling), the
 timed region is bracketed by barrier + synchronize, the slowest rank's time is used, and `value` is
 the whole-job aggregate.
@@ -160,6 +160,10 @@ def hbm_bound_layers(plan, units, kms, gen, x):
         if label == "c64_thin_bf16":
             nbytes = d.N * d.H * d.W * (d.Cin * 2 + d.Cout * 4)
             out[f"{label}:{d.Cin}->{d.Cout}@{d.H}x{d.W}"] = (nbytes, kms[u] * 1e-3)
+        if label == "upfuse_bf16":        # MFMA-bound, listed for its traffic: bf16 input once + the f32 image once
+            d2 = plan.args[i + 1].d
+            nbytes = d.N * d.H * d.W * d.Cin * 2 + d2.N * d2.H * d2.W * d2.Cout * 4
+            out[f"{label}:{d.Cin}->{d.Cout}->{d2.Cout}@{d2.H}x{d2.W}(mfma-bound)"] = (nbytes, kms[u] * 1e-3)
     reps = 10
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -304,7 +308,7 @@ def main():
                   for k, v in per_layer.items()}
         traffic = None       # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_summary.py)
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")))["kernels"]
+            pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))["kernels"]
             traffic = next(v["hbm_bytes"] for k, v in pm.items() if "resblock_c64_kernel" in k) if args.compute == "bf16" else None
         except Exception:
             traffic = None
@@ -321,7 +325,7 @@ def main():
                     "method": "HIP events (torch's current stream = the launch stream) around every launch of "
                               "instrumented forwards run right after the timed region, same process/data; achieved = "
                               "algorithmic conv FLOPs of the kernel's launches / their event time; traffic = FETCH_SIZE x2 "
-                              "+ WRITE_SIZE per launch from separate rocprofv3 --pmc passes (profiles/r1_pmc_traffic.json)"}
+                              "+ WRITE_SIZE per launch from separate rocprofv3 --pmc passes (profiles/r2_pmc_traffic.json)"}
         result = {
             "metric": "x4 SR output megapixels/sec (whole node)", "value": round(value, 2), "unit": "MP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
