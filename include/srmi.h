@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SRMI_VERSION 112 /* 0.1.1: dgrad / wgrad take a workspace (deterministic split-K), no float atomics left */
+#define SRMI_VERSION 113 /* 0.1.3: fused generator tail (srmi_conv2d_fwd_pair), SRCNN kernels, persistent chain removed */
 
 /* error codes */
 #define SRMI_OK 0
@@ -158,19 +158,6 @@ int srmi_conv2d_fwd_ws(const srmi_conv_args* a, void* ws, size_t ws_bytes, void*
 /* n fused convs enqueued back to back on `stream` from native code (one FFI crossing per forward
  * of `Generator`, P/srgan_model.py:27-39: 37 convs). */
 int srmi_conv2d_fwd_seq(const srmi_conv_args* a, int32_t n, void* stream);
-
-/* Persistent ResBlock chain (no counterpart in the reference, which runs one cuDNN call per layer; experimental, OFF by
- * default).  When enabled, srmi_conv2d_fwd_seq sends a run of >= 2 fusable pairs that feed each other (block i+1 reads
- * what block i wrote, every residual is its block's input, dense 64-channel tensors) out as ONE launch, provided every
- * 6 x 96 tile of the batch is resident at once (tiles <= CUs): a workgroup keeps its tile in LDS from block to block
- * and exchanges only the 2-pixel halo ring with its neighbour tiles through memory (agent-scope stores/loads, one flag
- * word per tile, BOUNDED spin).  Results are bit-identical to the per-block launches (tests/test_chain_gpu.py).
- * srmi_chain_enable returns the previous setting.  srmi_chain_status: *timeouts counts neighbour waits that gave up
- * since the library was loaded (an output was then wrong; stays 0 unless the GPU could not keep every tile resident);
- * it synchronises the device.  Chains that overlap in time on one GPU (two streams) are serialised by the hardware
- * (each needs every CU); up to 8 may be in flight. */
-int srmi_chain_enable(int32_t on);
-int srmi_chain_status(uint32_t* timeouts);
 
 /* ResBlock in one launch: y = residual + affine2(conv2(act(affine1(conv1(x))))); the intermediate stays
  * in LDS.  conv2->x is ignored; conv2->y must not alias conv1->x.  Returns SRMI_EUNSUPPORTED when the

@@ -324,19 +324,6 @@ int srmi_conv2d_fwd_seq(const srmi_conv_args* a, int32_t n, void* stream) {
     if (n < 0 || (n > 0 && !a)) { set_error("fwd_seq: bad arguments"); return SRMI_EINVAL; }
     for (int32_t i = 0; i < n; ++i) {
         if ((a[i].flags & SRMI_CONV_FUSE_NEXT) && i + 1 < n && can_fuse_pair(a + i, a + i + 1)) {
-            // a run of fusable pairs that feed each other goes out as ONE persistent launch when every tile fits the GPU
-            int32_t pairs = 1;
-            if (!resblock_chain_on()) pairs = 0;      // chain disabled: skip the scan
-            while (pairs && i + 2 * pairs + 1 < n && (a[i + 2 * pairs].flags & SRMI_CONV_FUSE_NEXT) &&
-                   can_fuse_pair(a + i + 2 * pairs, a + i + 2 * pairs + 1))
-                ++pairs;
-            const int m = pairs ? resblock_chain_length(a + i, pairs) : 0;
-            if (m >= 2) {
-                int rc = resblock_chain_launch(a + i, m, (hipStream_t)stream);
-                if (rc) return rc;
-                i += 2 * m - 1;
-                continue;
-            }
             int rc = resblock_launch(a[i], a[i + 1], (hipStream_t)stream);
             if (rc) return rc;
             ++i;
@@ -353,9 +340,6 @@ int srmi_conv2d_fwd_seq(const srmi_conv_args* a, int32_t n, void* stream) {
     }
     return SRMI_OK;
 }
-
-// investigation only, not declared in srmi.h: phase time stamps of the last traced chain launch (SRMI_DBG bit 16384)
-int srmi_debug_chain_trace(unsigned long long* out, int n) { return resblock_chain_trace(out, n); }
 
 int srmi_maxpool2x2_nhwc(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_cstride,
                          int32_t dtype, void* stream) {
@@ -388,18 +372,6 @@ int srmi_crop_augment_u8(const uint8_t* lr_pack, const uint8_t* gt_pack, const s
     if (!lr_pack || !gt_pack || !items || !lr_out || !gt_out) { set_error("crop_augment: NULL buffer"); return SRMI_EINVAL; }
     if ((long long)patch * scale > 0x7fff) { set_error("crop_augment: patch too large"); return SRMI_EINVAL; }
     return crop_augment(lr_pack, gt_pack, items, B, patch, scale, C, f32_arith, lr_out, gt_out, (hipStream_t)stream);
-}
-
-int srmi_chain_enable(int32_t on) {
-    return resblock_chain_enable(on);
-}
-
-int srmi_chain_status(uint32_t* timeouts) {
-    if (!timeouts) { set_error("chain_status: NULL argument"); return SRMI_EINVAL; }
-    unsigned c = 0;
-    int rc = resblock_chain_timeouts(&c);
-    *timeouts = c;
-    return rc;
 }
 
 int srmi_layout_convert(const void* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t src_layout,

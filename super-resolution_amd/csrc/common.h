@@ -131,11 +131,5 @@ int resblock_launch(const srmi_conv_args& a1, const srmi_conv_args& a2, hipStrea
 // fused generator tail: up conv 64->256 + PixelShuffle(2) + PReLU + last conv 64->3 + tanh (conv_upfuse_bf16.hip)
 bool upfuse_supported(const srmi_conv_desc& d1, const srmi_conv_desc& d2);
 int upfuse_launch(const srmi_conv_args& a1, const srmi_conv_args& a2, hipStream_t s);
-int resblock_chain_length(const srmi_conv_args* a, int npairs);      // 0: not a chain
-int resblock_chain_launch(const srmi_conv_args* a, int nblocks, hipStream_t s);
-int resblock_chain_timeouts(unsigned* count);
-int resblock_chain_enable(int on);
-bool resblock_chain_on();
-int resblock_chain_trace(unsigned long long* out, int n);
 
 }  // namespace srmi

@@ -88,8 +88,6 @@ SYMBOLS = {
     "srmi_conv2d_workspace_bytes": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_size_t)]),
     "srmi_conv2d_fwd_ws": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p, C.c_size_t, C.c_void_p]),
     "srmi_conv2d_fwd_seq": (C.c_int, [C.POINTER(ConvArgs), C.c_int32, C.c_void_p]),
-    "srmi_chain_status": (C.c_int, [C.POINTER(C.c_uint32)]),
-    "srmi_chain_enable": (C.c_int, [C.c_int32]),
     "srmi_conv2d_can_fuse": (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs)]),
     "srmi_conv2d_fwd_pair": (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), C.c_void_p]),
     "srmi_srcnn_layer_c1in": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),

@@ -71,22 +71,6 @@ def test_up_tail_fuzz(case):
     K.test_fused_up_tail_kernel(case)
 
 
-def _chain_cases(n, seed):
-    g = np.random.default_rng(seed)
-    out = []
-    while len(out) < n:
-        N, H, W = int(g.integers(1, 5)), int(g.integers(6, 60)), int(g.integers(65, 300))
-        if N * ((H + 5) // 6) * ((W + 95) // 96) <= 256:        # every tile resident at once, or the chain is not used
-            out.append(dict(N=N, H=H, W=W, nblk=int(g.integers(2, 7))))
-    return out
-
-
-@pytest.mark.parametrize("case", _chain_cases(8, seed=5))
-def test_chain_fuzz(case):
-    import test_chain_gpu as Cg
-    Cg.test_chain_matches_per_block_launches(case)
-
-
 def _srcnn_cases(n, seed):
     g = np.random.default_rng(seed)
     pw, c1, k9 = [], [], []
