@@ -32,7 +32,6 @@ struct C64Params {
     C64Epi epi;   // scale/shift/alpha/residual/output, store mode (0 plain, 1 PixelShuffle(2) CRD, 2 depth_to_space(2) DCR)
     int N, H, W, nchunk, in_cs;
     int tiles_x, tiles_y;
-    int stagger, first_round;   // start-time stagger of the first round's workgroups (0: none)
     int dbg;  // ablation switches (SRMI_DBG env, investigation only): 1 skip staging, 2 skip K loop, 4 skip epilogue
 };
 
@@ -74,15 +73,6 @@ __global__ __launch_bounds__(NW * 64, WGPC) void conv_c64_kernel(C64Params p) {
 
     // XCD-aware tile order: consecutive workgroup ids go round-robin to the 8 XCDs (one L2 each), so give each
     // XCD a CONTIGUOUS run of tiles - vertically adjacent tiles then share their halo rows through one L2.
-    if (p.stagger > 0) {
-        // Timing experiment (SRMI_STAGGER=n, off by default): hold the workgroups of the first round back by 0 .. n-1
-        // micro-delays (~1.1 us each, hashed from the workgroup id) so that the CUs do not stage, compute and store in
-        // lockstep across the chip.  Measured: no gain on the 4-round up conv (168.7 vs 172 us at n = 8).
-        if (blockIdx.x < (unsigned)p.first_round) {
-            const int dly = (int)(((blockIdx.x * 2654435761u) >> 16) % (unsigned)p.stagger);
-            for (int i = 0; i < dly; ++i) __builtin_amdgcn_s_sleep(42);
-        }
-    }
     int b = blockIdx.x;
     if ((gridDim.x & 7) == 0 && !(p.dbg & 32)) b = (b & 7) * (gridDim.x >> 3) + (b >> 3);
     const int tx = b % p.tiles_x; b /= p.tiles_x;
@@ -362,15 +352,12 @@ int c64_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     const long long nb = (long long)d.N * p.tiles_x * p.tiles_y;
     if (nb > 0x7fffffffLL) { set_error("c64_bf16: grid too large"); return SRMI_EINVAL; }
     const bool w4 = (p.dbg & 256) != 0;    // ablation: the 4-wave variants
-    p.stagger = 0; p.first_round = 256;
-    { const char* e = getenv("SRMI_STAGGER"); if (e) p.stagger = atoi(e); }
     // Two workgroups per CU (6 x 48 tiles) once the launch has several rounds of them: they drift out of phase and
     // hide each other's staging, epilogue and store waits.  (One round runs in lockstep: it gains nothing with several
     // channel chunks - 64->256 at 96x96: 47.5 -> 48.8 us - and 1 us with one - 64->64 at 96x96: 22.5 -> 21.5 us.)
     const long long nb2 = (long long)d.N * ((d.W + 47) / 48) * ((d.H + 5) / 6);
     const bool two = tile == 0 && p.nchunk <= 4 && !w4 && ((p.dbg & (1 << 21)) ? false : ((p.dbg & (1 << 22)) ? true : nb2 >= (p.nchunk == 1 ? 512 : 1024)));
     if (two) {
-        p.first_round = 512;
         p.tiles_x = (d.W + 47) / 48; p.tiles_y = (d.H + 5) / 6;
         hipLaunchKernelGGL((conv_c64_kernel<6, 3, 4, 3, 2, 2, 4>), dim3((unsigned)nb2), dim3(256), 0, s, p);
     } else if (tile == 0 && w4) hipLaunchKernelGGL((conv_c64_kernel<6, 6, 4>), dim3((unsigned)nb), dim3(256), 0, s, p);

@@ -9,9 +9,9 @@
 // reads per MFMA step; the tile is kept twice, the second copy shifted by one pixel, so that every pair is
 // dword-aligned in the copy that matches the parity of the lane's column.  The 12 read addresses are per-lane
 // constants that only advance by one tile row per step.  The weights stay in registers as A
-// fragments (48 VGPRs).  The M rows are PERMUTED at pack time (row 4 q + e of M tile mt = channel 16 q + 4 mt + e) so
-// that a lane ends up with 16 CONSECUTIVE channels of its pixel: two 16-byte stores, and the four lanes of a pixel write
-// one whole 128-byte line.
+// fragments (48 VGPRs).  The M rows are PERMUTED at pack time so that a lane ends up with channels 8 q .. 8 q + 7
+// and 32 + 8 q .. 32 + 8 q + 7 of its pixel: two 16-byte stores, each of which makes 64 contiguous bytes with the other
+// three lanes of the pixel (whole 32-byte sectors; 16 x 8 tiles: more, shorter workgroups measured faster than 16 x 64 rows).
 //
 // The layer is bound by its output stream: 4 B in, 128 B out per pixel and 64 channels (algorithmic bytes).
 #include <type_traits>
@@ -28,9 +28,9 @@ struct K9c1Params {
     int act; float act_param;
 };
 
-constexpr int K9C1_TH = 16, K9C1_TW = 64, K9C1_LH = K9C1_TH + 8, K9C1_LW = K9C1_TW + 10;      // (even; column +9 is read, weight 0)
+constexpr int K9C1_TH = 8, K9C1_TW = 64, K9C1_LH = K9C1_TH + 8, K9C1_LW = K9C1_TW + 10;      // (even; column +9 is read, weight 0)
 
-// A fragments [group][mt][ks][lane][8]: lane = 16 kq + r, row r of M tile mt = channel 64 g + 16 (r >> 2) + 4 mt + (r & 3),
+// A fragments [group][mt][ks][lane][8]: lane = 16 kq + r, row r of M tile mt = channel 64 g + 32 (mt >> 1) + 8 (r >> 2) + 4 (mt & 1) + (r & 3),
 // K index 32 ks + 8 kq + i = 10 dy + dx, zero for dx = 9 and from 90 on
 __global__ void k9c1_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cout) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -38,7 +38,7 @@ __global__ void k9c1_pack_kernel(const float* __restrict__ w, bf16_t* __restrict
     const int e = i & 7, lane = (i >> 3) & 63, f = i >> 9;
     const int ks = f % 3, mt = (f / 3) & 3, g = f / 12;
     const int r = lane & 15, kq = lane >> 4;
-    const int ch = 64 * g + 16 * (r >> 2) + 4 * mt + (r & 3);
+    const int ch = 64 * g + 32 * (mt >> 1) + 8 * (r >> 2) + 4 * (mt & 1) + (r & 3);
     const int kk = 32 * ks + 8 * kq + e;
     const int dy = kk / 10, dx = kk - 10 * dy;
     out[i] = (kk < 90 && dx < 9) ? f2bf(w[(size_t)ch * 81 + dy * 9 + dx]) : (bf16_t)0;
@@ -74,12 +74,12 @@ __global__ __launch_bounds__(256) void k9c1_kernel(K9c1Params p) {
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) a[mt][ks] = *(const bf16x8*)(p.w + ((size_t)((g * 4 + mt) * 3 + ks) * 64 + lane) * 8);
-    // this lane's 16 output channels: 64 g + 16 q + (4 mt + e)
+    // this lane's 16 output channels: 64 g + 8 q + 0..7 (M tiles 0, 1) and 64 g + 32 + 8 q + 0..7 (M tiles 2, 3)
     f32x4 sc[4], sh[4];
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
-        sc[mt] = *(const f32x4*)(p.scale + 64 * g + 16 * q + 4 * mt);
-        sh[mt] = *(const f32x4*)(p.shift + 64 * g + 16 * q + 4 * mt);
+        sc[mt] = *(const f32x4*)(p.scale + 64 * g + 32 * (mt >> 1) + 8 * q + 4 * (mt & 1));
+        sh[mt] = *(const f32x4*)(p.shift + 64 * g + 32 * (mt >> 1) + 8 * q + 4 * (mt & 1));
     }
     const float slope = p.act == SRMI_ACT_PRELU ? p.alpha[0] : p.act == SRMI_ACT_LRELU ? p.act_param
                       : p.act == SRMI_ACT_RELU ? 0.f : 1.f;
@@ -131,9 +131,9 @@ __global__ __launch_bounds__(256) void k9c1_kernel(K9c1Params p) {
                 o[mt >> 1][2 * (mt & 1) + h] = pack_bf2(z[0], z[1]);
             }
         if (x < p.W) {
-            bf16_t* dst = p.y + ((size_t)((size_t)n * p.H + y0 + k) * p.W + x) * p.out_cs + p.out_co + 64 * g + 16 * q;
-            __builtin_nontemporal_store(o[0], (u32x4*)dst);
-            __builtin_nontemporal_store(o[1], (u32x4*)(dst + 8));
+            bf16_t* dst = p.y + ((size_t)((size_t)n * p.H + y0 + k) * p.W + x) * p.out_cs + p.out_co + 64 * g + 8 * q;
+            __builtin_nontemporal_store(o[0], (u32x4*)dst);             // 4 lanes = 64 contiguous bytes of the pixel's line
+            __builtin_nontemporal_store(o[1], (u32x4*)(dst + 32));      // (plain stores: the same time within noise)
         }
     }
     };

@@ -14,6 +14,7 @@ or write through ``with torch.no_grad(): p.copy_(...)`` instead, which does bump
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import torch
 import torch.nn as nn
@@ -259,26 +260,36 @@ class DiscriminatorPlan:
 
 
 class PlanCache:
+    """Plans per (device, stream, input shape, compute mode).  A plan owns its activation buffers and its argument
+    array, so two forwards that share a plan must not overlap: the device AND the stream are part of the key (forwards
+    of one module on two streams get a plan each; nn.DataParallel replicas share this object through the __dict__
+    copy and are told apart by the device), and the table itself is guarded by a lock.  Two host threads driving the
+    SAME stream through the same module still serialise on the GPU, but their `run()` calls rewrite one argument
+    array: give each thread its own stream."""
+
     def __init__(self, factory):
         self.factory = factory
         self.plans = {}
+        self.lock = threading.Lock()
 
     def get(self, module, N, H, W, compute):
-        # the device is part of the key: nn.DataParallel replicas share this object through the __dict__ copy
         dev = next(module.parameters()).device
-        key = (dev.index, N, H, W, compute)
+        stream = torch.cuda.current_stream(dev).cuda_stream if dev.type == "cuda" else 0
+        key = (dev.index, stream, N, H, W, compute)
         sig = _sig(module)
-        hit = self.plans.get(key)
-        if hit is not None and hit[0] == sig:
-            return hit[1]
-        if hit is None and len(self.plans) >= 8:   # bound the buffers held for stale shapes
-            self.plans.pop(next(iter(self.plans)))
-        plan = self.factory(module, N, H, W, compute)
-        self.plans[key] = (sig, plan)
-        return plan
+        with self.lock:
+            hit = self.plans.get(key)
+            if hit is not None and hit[0] == sig:
+                return hit[1]
+            if hit is None and len(self.plans) >= 8:   # bound the buffers held for stale shapes / streams
+                self.plans.pop(next(iter(self.plans)))
+            plan = self.factory(module, N, H, W, compute)
+            self.plans[key] = (sig, plan)
+            return plan
 
     def clear(self):
-        self.plans.clear()
+        with self.lock:
+            self.plans.clear()
 
     # plans hold device buffers and ctypes pointers: never copied or pickled with the module
     def __deepcopy__(self, memo):
@@ -286,3 +297,7 @@ class PlanCache:
 
     def __getstate__(self):
         return {"factory": self.factory, "plans": {}}
+
+    def __setstate__(self, state):
+        self.factory, self.plans = state["factory"], {}
+        self.lock = threading.Lock()
