@@ -229,17 +229,24 @@ __global__ __launch_bounds__(256) void c1_kernel(C1Params p) {
     // A operand: row (j + 15 - m) of table (dy, ks); m = this lane's output column inside the block
     const unsigned char* abase = tab + (15 - nl) * 64 + q * 16;
 
-    auto load_row = [&](bf16x8 (&b)[16], int r, int ks) {
+    // A step = one input row, one PART of its 16 block columns: all of them with 32 channels; with 64 channels the
+    // columns 0..7 or 8..15 with BOTH channel halves, so that the two 64-byte halves of a pixel's 128-byte line are
+    // fetched back to back (by K half they would be fetched a whole step apart: every line twice through the L1).
+    constexpr int JP = 16 / KS;                        // block columns per step; 16 operand registers either way
+    auto load_row = [&](bf16x8 (&b)[16], int r, int part) {
         const bool ok = r >= 0 && r < p.H;
         const __amdgpu_buffer_rsrc_t res = __builtin_amdgcn_make_buffer_rsrc(
             (void*)(img + (size_t)(ok ? r : 0) * row_bytes), 0, ok ? row_bytes : 0u, 0x00020000);
 #pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int xin = xb + j;
-            unsigned off = (unsigned)(xin * stride + 64 * ks + 16 * q);
-            if (j < PAD && xin < 0) off = 0x80000000u;         // left of the image: zero (right of it: past num_records)
-            b[j] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(res, off, 0, 0));
-        }
+        for (int jj = 0; jj < JP; ++jj)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int j = part * JP + jj;
+                const int xin = xb + j;
+                unsigned off = (unsigned)(xin * stride + 64 * ks + 16 * q);
+                if (j < PAD && xin < 0) off = 0x80000000u;     // left of the image: zero (right of it: past num_records)
+                b[jj * KS + ks] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(res, off, 0, 0));
+            }
     };
 
     f32x4 acc[K];
@@ -248,15 +255,18 @@ __global__ __launch_bounds__(256) void c1_kernel(C1Params p) {
     const float sc0 = p.scale[0], sh0 = p.shift[0];
     const float al0 = p.act == SRMI_ACT_PRELU ? p.alpha[0] : 0.f;
 
-    // one input row (one K half of it): k x 16 banded MFMAs; after the last half the oldest accumulator is a finished row
-    auto compute = [&](const bf16x8 (&b)[16], int ir, int ks, bool last) {
+    // one step: k x 16 banded MFMAs; after the last part of a row the oldest accumulator is a finished row
+    auto compute = [&](const bf16x8 (&b)[16], int ir, int part, bool last) {
 #pragma unroll
         for (int dy = 0; dy < K; ++dy)
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const bf16x8 a = *(const bf16x8*)(abase + ((dy * KS) * 31 + j) * 64 + ks * (31 * 64));
-                acc[dy] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[j], acc[dy], 0, 0, 0);
-            }
+            for (int jj = 0; jj < JP; ++jj)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) {
+                    const int j = part * JP + jj;
+                    const bf16x8 a = *(const bf16x8*)(abase + ((dy * KS + ks) * 31 + j) * 64);
+                    acc[dy] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b[jj * KS + ks], acc[dy], 0, 0, 0);
+                }
         // keep only a few banded operands in flight: {4 LDS reads} {1 MFMA, 1 LDS read} x (16 K - 4) {4 MFMAs}
         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
         sched_pairs<0, 16 * K - 4>();
@@ -286,14 +296,14 @@ __global__ __launch_bounds__(256) void c1_kernel(C1Params p) {
         acc[0] = (f32x4){0.f, 0.f, 0.f, 0.f};
     };
 
-    // steps = (input row, K half), double-buffered by hand: the loads of step s + 1 are in flight during the MFMAs of step s
+    // steps = (input row, part), double-buffered by hand: the loads of step s + 1 are in flight during the MFMAs of step s
     const int nrow = (r1 - r0) + K - 1;                // input rows r0 - PAD .. r1 + PAD - 1
     const int S = nrow * KS;
     bf16x8 b0[16], b1[16];
     load_row(b0, r0 - PAD, 0);
     int s = 0;
     for (; s + 1 < S; s += 2) {
-        // s is even: K half 0 in b0, K half KS - 1 in b1 (KS = 1: two rows)
+        // s is even: part 0 in b0, part KS - 1 in b1 (KS = 1: two rows)
         load_row(b1, r0 - PAD + (s + 1) / KS, KS - 1);
         compute(b0, s / KS, 0, KS == 1);
         if (s + 2 < S) load_row(b0, r0 - PAD + (s + 2) / KS, 0);
