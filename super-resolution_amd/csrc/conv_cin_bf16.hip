@@ -32,8 +32,8 @@ struct CinParams {
 
 constexpr int CIN_WRING = 4;
 
-template <int TH, int TWT, int NCT, int NW>
-__global__ __launch_bounds__(NW * 64, 1) void conv_cin_kernel(CinParams p) {
+template <int TH, int TWT, int NCT, int NW, int WGPC = 1>
+__global__ __launch_bounds__(NW * 64, WGPC) void conv_cin_kernel(CinParams p) {
     constexpr int NTH = NW * 64;
     constexpr int TW = TWT * 16;
     constexpr int NPT = TH * TWT;
@@ -334,14 +334,20 @@ int cin_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     if (d.N == 0 || d.H == 0 || d.W == 0) return SRMI_OK;
     const int nct = cin_nct(d);
     const unsigned gy = (unsigned)(d.Cout / (16 * nct));
-    const int tile = pick_tile3x3(d.N, d.H, d.W);
-    static const int th[3] = {6, 8, 4}, tw[3] = {96, 64, 32};
+    int tile = pick_tile3x3(d.N, d.H, d.W);
+    static const int th[4] = {6, 8, 4, 8}, tw[4] = {96, 64, 32, 32};
+    // 32 output channels per workgroup and several rounds of tiles: 8 x 32 tiles with 4 waves need 77 KB of LDS, so TWO
+    // workgroups share a CU and one's synchronous chunk staging runs under the other's MFMAs (cfg4 RRDB-23: 8.13 ->
+    // 7.71 ms; the same idea at 64 channels per workgroup - 8 x 16 tiles - was slower, 7.89 -> 8.09 ms).  SRMI_DBG bit 15: off.
+    if (nct == 2 && tile != 2 && !(dbg_flags() & (1 << 15)) &&
+        (long long)d.N * ((d.W + 31) / 32) * ((d.H + 7) / 8) >= 1024) tile = 3;
     p.tiles_x = (d.W + tw[tile] - 1) / tw[tile]; p.tiles_y = (d.H + th[tile] - 1) / th[tile];
     const long long nb = (long long)d.N * p.tiles_x * p.tiles_y;
     if (nb > 0x7fffffffLL || gy > 65535u) { set_error("cin_bf16: grid too large"); return SRMI_EINVAL; }
     const dim3 grid((unsigned)nb, gy);
     // the two big tiles run with 8 waves (two per SIMD hide each other's LDS / barrier / staging bubbles)
-    if (tile == 0 && nct == 4) hipLaunchKernelGGL((conv_cin_kernel<6, 6, 4, 8>), grid, dim3(512), 0, s, p);
+    if (tile == 3) hipLaunchKernelGGL((conv_cin_kernel<8, 2, 2, 4, 2>), grid, dim3(256), 0, s, p);
+    else if (tile == 0 && nct == 4) hipLaunchKernelGGL((conv_cin_kernel<6, 6, 4, 8>), grid, dim3(512), 0, s, p);
     else if (tile == 0) hipLaunchKernelGGL((conv_cin_kernel<6, 6, 2, 8>), grid, dim3(512), 0, s, p);
     else if (tile == 1 && nct == 4) hipLaunchKernelGGL((conv_cin_kernel<8, 4, 4, 8>), grid, dim3(512), 0, s, p);
     else if (tile == 1) hipLaunchKernelGGL((conv_cin_kernel<8, 4, 2, 8>), grid, dim3(512), 0, s, p);

@@ -13,7 +13,8 @@
 //     tile that is 625 pixels = 40 MFMA pixel tiles (5 per wave) for 576 useful ones: 1.11x the up conv's MFMAs is the
 //     price of never storing T (the ring is recomputed by neighbouring workgroups);
 //   * one 64-channel chunk of the up conv's output IS one sub-pixel (i, j) of PixelShuffle(2) with all 64 channels of T
-//     (CRD order: conv channel = 4 c + 2 i + j), and the accumulator layout of the MFMA gives a lane 16 channels of one
+//     (CRD order: conv channel = 4 c + 2 i + j; Keras depth_to_space, DCR: 64 (2 i + j) + c - the packing of the up
+//     conv's weights follows the order, the kernel does not care), and the accumulator layout of the MFMA gives a lane 16 channels of one
 //     pixel - after bias + PReLU + bf16 rounding (the same values the unfused path stores) these registers ARE the B
 //     operand of the last conv's MFMA, with no data movement;
 //   * the last conv runs in SCATTER form: for a T pixel, M = 27 rows (9 taps x 3 output channels), K = 64 channels:
@@ -348,9 +349,8 @@ __global__ __launch_bounds__(NW * 64, 1) void upfuse_kernel(UpFuseParams p) {
 bool upfuse_supported(const srmi_conv_desc& d1, const srmi_conv_desc& d2) {
     if (dbg_flags() & (1 << 13)) return false;                       // ablation / A-B switch: run the two launches
     if (!c64_supported(d1) || !thin_supported(d2)) return false;
-    if (d1.Cout != 256 || d1.shuffle != 2 || d1.shuffle_order != SRMI_SHUFFLE_CRD) return false;
+    if (d1.Cout != 256 || d1.shuffle != 2) return false;      // (CRD and DCR orders: a 64-channel chunk is one sub-pixel in both)
     if ((d1.out_cstride && d1.out_cstride != 64) || d1.out_coffset) return false;
-    if (d1.act == SRMI_ACT_PRELU && d1.alpha_per_channel) return false;      // (per-channel slopes after the shuffle: not wired)
     if (d2.Cout != 3 || d2.N != d1.N || d2.H != 2 * d1.H || d2.W != 2 * d1.W) return false;
     if ((d2.in_cstride && d2.in_cstride != 64)) return false;
     if (d2.out_layout != SRMI_NCHW || d2.out_dtype != SRMI_F32) return false;
@@ -370,8 +370,9 @@ int upfuse_launch(const srmi_conv_args& a1, const srmi_conv_args& a2, hipStream_
     UpFuseParams p;
     p.x = (const bf16_t*)a1.x; p.w = (const bf16_t*)a1.w;
     p.epi.scale = a1.scale; p.epi.shift = a1.shift; p.epi.alpha = a1.alpha; p.epi.res = nullptr; p.epi.y = nullptr;
-    p.epi.H = d1.H; p.epi.W = d1.W; p.epi.Cout = 256; p.epi.out_cs = 64; p.epi.out_co = 0; p.epi.mode = C64_CRD;
-    p.epi.act = d1.act; p.epi.act_param = d1.act_param; p.epi.alpha_pc = 0;
+    p.epi.H = d1.H; p.epi.W = d1.W; p.epi.Cout = 256; p.epi.out_cs = 64; p.epi.out_co = 0;
+    p.epi.mode = d1.shuffle_order == SRMI_SHUFFLE_DCR ? C64_DCR : C64_CRD;
+    p.epi.act = d1.act; p.epi.act_param = d1.act_param; p.epi.alpha_pc = d1.alpha_per_channel;
     p.w7 = (const bf16_t*)a2.w; p.scale7 = a2.scale; p.shift7 = a2.shift; p.alpha7 = a2.alpha;
     p.y = (float*)a2.y;
     p.N = d1.N; p.H = d1.H; p.W = d1.W; p.in_cs = d1.in_cstride ? d1.in_cstride : 64;

@@ -131,7 +131,8 @@ class RRDBPlan(_Plan):
         x, h, w = t, H, W
         for j in range(2):
             y = s.buf(N, 2 * h, 2 * w, nf)
-            s.add((m.up[j], None, m.up_act[j]), x, y, N, h, w, shuffle=2, shuffle_order=L.SHUFFLE_DCR)
+            # the second up conv and the tail conv may run as ONE launch (srmi_conv2d_fwd_pair, SRMI_FUSE_UPTAIL)
+            s.add((m.up[j], None, m.up_act[j]), x, y, N, h, w, shuffle=2, shuffle_order=L.SHUFFLE_DCR, fuse_next=(j == 1))
             x, h, w = y, 2 * h, 2 * w
         self.out_shape = (N, m.tail.out_channels, h, w)
         y0 = torch.empty(self.out_shape, dtype=torch.float32, device=dev)
@@ -201,7 +202,8 @@ class KerasSRGANPlan(_Plan):
         x, h, w = t, H, W
         for j in range(2):
             y = s.buf(N, 2 * h, 2 * w, nf)
-            s.add((m.up[j], None, m.up_act[j]), x, y, N, h, w, shuffle=2, shuffle_order=L.SHUFFLE_DCR)
+            # the second up conv and the tail conv may run as ONE launch (srmi_conv2d_fwd_pair, SRMI_FUSE_UPTAIL)
+            s.add((m.up[j], None, m.up_act[j]), x, y, N, h, w, shuffle=2, shuffle_order=L.SHUFFLE_DCR, fuse_next=(j == 1))
             x, h, w = y, 2 * h, 2 * w
         self.out_shape = (N, m.tail.out_channels, h, w)
         y0 = torch.empty(self.out_shape, dtype=torch.float32, device=dev)
@@ -314,7 +316,8 @@ class UNetSRGANPlan:
         for j in range(2):
             co = m.up[j].out_channels
             y = s.buf(N, 2 * h, 2 * w, co // 4)
-            s.add((m.up[j], None, m.up_act[j]), x, y, N, h, w, shuffle=2, shuffle_order=L.SHUFFLE_DCR)
+            # the second up conv and the tail conv may run as ONE launch (srmi_conv2d_fwd_pair, SRMI_FUSE_UPTAIL)
+            s.add((m.up[j], None, m.up_act[j]), x, y, N, h, w, shuffle=2, shuffle_order=L.SHUFFLE_DCR, fuse_next=(j == 1))
             x, h, w = y, 2 * h, 2 * w
         self.out_shape = (N, m.tail.out_channels, h, w)
         y0 = torch.empty(self.out_shape, dtype=torch.float32, device=dev)
@@ -427,7 +430,8 @@ class AutoencoderSRGANPlan(UNetSRGANPlan):
         for j in range(2):
             co = m.up[j].out_channels
             y = s.buf(N, 2 * h, 2 * w, co // 4)
-            s.add((m.up[j], None, m.up_act[j]), x, y, N, h, w, shuffle=2, shuffle_order=L.SHUFFLE_DCR)
+            # the second up conv and the tail conv may run as ONE launch (srmi_conv2d_fwd_pair, SRMI_FUSE_UPTAIL)
+            s.add((m.up[j], None, m.up_act[j]), x, y, N, h, w, shuffle=2, shuffle_order=L.SHUFFLE_DCR, fuse_next=(j == 1))
             x, h, w = y, 2 * h, 2 * w
         self.out_shape = (N, m.tail.out_channels, h, w)
         y0 = torch.empty(self.out_shape, dtype=torch.float32, device=dev)
@@ -536,7 +540,8 @@ class ResUNetSRGANPlan(UNetSRGANPlan):
         for j in range(2):
             co = m.up[j].out_channels
             y = s.buf(N, 2 * h, 2 * w, co // 4)
-            s.add((m.up[j], None, m.up_act[j]), x, y, N, h, w, shuffle=2, shuffle_order=L.SHUFFLE_DCR)
+            # the second up conv and the tail conv may run as ONE launch (srmi_conv2d_fwd_pair, SRMI_FUSE_UPTAIL)
+            s.add((m.up[j], None, m.up_act[j]), x, y, N, h, w, shuffle=2, shuffle_order=L.SHUFFLE_DCR, fuse_next=(j == 1))
             x, h, w = y, 2 * h, 2 * w
         self.out_shape = (N, m.tail.out_channels, h, w)
         y0 = torch.empty(self.out_shape, dtype=torch.float32, device=dev)

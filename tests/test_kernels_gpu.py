@@ -451,6 +451,9 @@ def test_fused_resblock_kernel(case):
     dict(N=1, H=16, W=49, alpha=1.0),
     dict(N=1, H=1, W=1),
     dict(N=3, H=2, W=200),
+    dict(N=1, H=25, W=30, dcr=True, alpha_pc=True),          # Keras depth_to_space order + per-channel PReLU (RRDBNet tail)
+    dict(N=2, H=9, W=50, dcr=True),
+    dict(N=1, H=12, W=26, alpha_pc=True),
 ])
 def test_fused_up_tail_kernel(case):
     """conv3x3 64->256 -> PixelShuffle(2) -> PReLU -> conv3x3 64->3 -> tanh in one launch (srmi_conv2d_fwd_pair,
@@ -467,11 +470,15 @@ def test_fused_up_tail_kernel(case):
     w2 = torch.from_numpy((g.standard_normal((3, 64, 3, 3)) / 24.0).astype(np.float32)).bfloat16().float()
     sc1 = torch.ones(256); sh1 = torch.from_numpy(g.uniform(-0.3, 0.3, 256).astype(np.float32))
     sc2 = torch.ones(3); sh2 = torch.from_numpy(g.uniform(-0.3, 0.3, 3).astype(np.float32))
+    dcr, apc = case.get("dcr", False), case.get("alpha_pc", False)
     alpha = torch.tensor([case.get("alpha", 0.25)])
-    t_ref = _ref_fused(x, w1, sc1, sh1, L.ACT_PRELU, 0.0, alpha, None, 1, 1, 2, False).float().bfloat16().float()
+    if apc:        # one slope per conv channel (a post-shuffle PReLU(64) arrives expanded like this, engine._Seq.add)
+        alpha = torch.from_numpy(g.uniform(-0.2, 0.6, 256).astype(np.float32))
+    t_ref = _ref_fused(x, w1, sc1, sh1, L.ACT_PRELU, 0.0, alpha, None, 1, 1, 2, dcr).float().bfloat16().float()
     ref = _ref_fused(t_ref, w2, sc2, sh2, act2, 0.0, None, None, 1, 1, 1, False)
 
-    d1 = Fn.make_desc(N, H, W, 64, 256, 3, in_dtype=L.BF16, out_dtype=L.BF16, compute=L.COMPUTE_BF16, act=L.ACT_PRELU, shuffle=2)
+    d1 = Fn.make_desc(N, H, W, 64, 256, 3, in_dtype=L.BF16, out_dtype=L.BF16, compute=L.COMPUTE_BF16, act=L.ACT_PRELU, shuffle=2,
+                      shuffle_order=L.SHUFFLE_DCR if dcr else L.SHUFFLE_CRD, alpha_per_channel=int(apc))
     d2 = Fn.make_desc(N, 2 * H, 2 * W, 64, 3, 3, in_dtype=L.BF16, out_dtype=L.F32, out_layout=L.NCHW, compute=L.COMPUTE_BF16, act=act2)
     assert L.kernel_name(d1) == "c64_bf16" and L.kernel_name(d2) == "c64_thin_bf16"
     xd = x.permute(0, 2, 3, 1).contiguous().bfloat16().to(DEV)

@@ -80,6 +80,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--compute", default="bf16")
     ap.add_argument("--blocks", type=int, default=23)
+    ap.add_argument("--layers", action="store_true", help="per-layer table for cfg4 too (long)")
     ap.add_argument("--only", default="", help="comma list of cfg2,cfg5,cfg4 (default: all)")
     args = ap.parse_args()
     only = set(filter(None, args.only.split(",")))
@@ -117,7 +118,7 @@ def main():
         x4 = torch.rand(8, 3, 256, 256, generator=g) * 2 - 1
         lr_px = 8 * 256 * 256
         run(f"cfg4 RRDBNet {args.blocks} blocks, 8x3x256x256 -> x4", RRDBNet(num_blocks=args.blocks), x4, lr_px * 16,
-            lr_px * 2.0 * (175_104 * args.blocks + 803_520), args.steps, args.warmup, args.compute)
+            lr_px * 2.0 * (175_104 * args.blocks + 803_520), args.steps, args.warmup, args.compute, per_layer=args.layers)
 
 
 if __name__ == "__main__":
