@@ -450,7 +450,11 @@ int resblock_launch(const srmi_conv_args& a1, const srmi_conv_args& a2, hipStrea
     } else if (t12) {
         p.tiles_x = (d1.W + 47) / 48; p.tiles_y = (d1.H + 11) / 12;
         if (nb48 > 0x7fffffffLL) { set_error("resblock_bf16: grid too large"); return SRMI_EINVAL; }
-        hipLaunchKernelGGL((resblock_c64_kernel<12, 3, 8, 4, 1, 1>), dim3((unsigned)nb48), dim3(512), 0, s, p);
+        // weight ring: three tap-sized slots (half the hand-off barriers of four K-step slots; the padded pitch still fits
+        // at this tile: 157 KB) - 29.4 vs 29.75 us per launch in three alternating runs; SRMI_DBG bit 22: the K-step ring
+        // (four tap slots with an 8-pixel pitch, 149 KB: 29.0 vs 28.2 us - the narrower pitch costs more than the deeper ring gains)
+        if (p.dbg & (1 << 22)) hipLaunchKernelGGL((resblock_c64_kernel<12, 3, 8, 4, 1, 1>), dim3((unsigned)nb48), dim3(512), 0, s, p);
+        else hipLaunchKernelGGL((resblock_c64_kernel<12, 3, 8, 3, 1, 2>), dim3((unsigned)nb48), dim3(512), 0, s, p);
     } else if (big) {
         p.tiles_x = (d1.W + 95) / 96; p.tiles_y = (d1.H + 5) / 6;
         const long long nb = (long long)d1.N * p.tiles_x * p.tiles_y;
