@@ -50,6 +50,7 @@ struct C64Epi {
     const bf16_t* res; bf16_t* y;
     int H, W, Cout, out_cs, out_co, mode;
     int act; float act_param; int alpha_pc;
+    int res_cs = 0;      // channels per pixel of the residual buffer (0 = dense = final channel count): a channel slice of a wider buffer
 };
 
 // 0: no activation, 1: one slope in [0, 1] for every channel (max form), 2: general (compare + select).  Wave-uniform.
@@ -163,7 +164,8 @@ __device__ __forceinline__ void c64_epilogue(const f32x4 (&acc)[PT][4], const fl
             r[k][0] = (u32x4){0u, 0u, 0u, 0u};
             r[k][1] = (u32x4){0u, 0u, 0u, 0u};
             if (ok[k]) {
-                const bf16_t* rp = o.res + rowpix[k] * Cf + (unsigned)(ocol[k] * Cf + cbase);
+                const int rcs = o.res_cs ? o.res_cs : Cf;
+                const bf16_t* rp = o.res + rowpix[k] * rcs + (unsigned)(ocol[k] * rcs + cbase);
                 r[k][0] = *(const u32x4*)rp;
                 r[k][1] = *(const u32x4*)(rp + 32);
             }

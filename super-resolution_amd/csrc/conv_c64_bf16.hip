@@ -290,7 +290,7 @@ __global__ void c64_pack_kernel(const float* __restrict__ w, bf16_t* __restrict_
 
 bool c64_supported(const srmi_conv_desc& d) {
     if (d.compute != SRMI_COMPUTE_BF16) return false;
-    if (d.res_cstride && d.res_cstride != d.Cout / (d.shuffle * d.shuffle)) return false;   // dense residual only
+    if (d.res_cstride && (d.res_cstride % 8 != 0 || d.res_cstride < d.Cout / (d.shuffle * d.shuffle))) return false;   // (16-byte residual reads)
     if (d.kh != 3 || d.kw != 3 || d.stride != 1 || d.pad != 1 || d.Cin != 64) return false;
     if (d.Cout % 64 != 0 || d.Cout <= 0 || d.Cout > 64 * C64_MAX_CHUNKS) return false;
     if (d.in_dtype != SRMI_BF16 || d.out_dtype != SRMI_BF16) return false;
@@ -336,7 +336,7 @@ int c64_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     C64Params p;
     p.x = (const bf16_t*)a.x; p.w = (const bf16_t*)a.w;
     p.epi.scale = a.scale; p.epi.shift = a.shift; p.epi.alpha = a.alpha;
-    p.epi.res = (const bf16_t*)a.residual; p.epi.y = (bf16_t*)a.y;
+    p.epi.res = (const bf16_t*)a.residual; p.epi.y = (bf16_t*)a.y; p.epi.res_cs = d.res_cstride;
     p.epi.H = d.H; p.epi.W = d.W; p.epi.Cout = d.Cout; p.epi.out_cs = g.out_cs; p.epi.out_co = d.out_coffset;
     p.epi.mode = c64_mode(d);
     p.epi.act = d.act; p.epi.act_param = d.act_param; p.epi.alpha_pc = d.alpha_per_channel;

@@ -400,6 +400,7 @@ bool resblock_supported(const srmi_conv_desc& d1, const srmi_conv_desc& d2) {
     if (d1.N != d2.N || d1.H != d2.H || d1.W != d2.W) return false;
     if (d1.out_cstride && d1.out_cstride != 64) return false;   // T must be a plain 64-channel tensor
     if (d1.out_coffset || (d2.in_cstride && d2.in_cstride != 64)) return false;
+    if (d2.res_cstride && d2.res_cstride != 64) return false;   // dense residual only
     // the staging addresses one image through a 32-bit buffer descriptor with two out-of-range markers
     if ((unsigned long long)d1.H * d1.W * (d1.in_cstride ? d1.in_cstride : 64) * 2 > (1ull << 30)) return false;
     return true;

@@ -103,19 +103,18 @@ class RRDBPlan(_Plan):
         nf, g, nd = m.n_feats, m.growth, m.num_dense_layers
         ctot = nf + nd * g
         lrelu = nn.LeakyReLU(0.2)
-        # block b works in cat[b & 1]: x in channels [0, nf), dense outputs appended behind it
-        cat = [s.buf(N, H, W, ctot), s.buf(N, H, W, ctot)]
-        first = s.buf(N, H, W, nf)
-        s.add((m.head, None, m.head_act), None, first, N, H, W, in_layout=L.NCHW, in_dtype=L.F32)
+        # block b works in a concat buffer: x in channels [0, nf), dense outputs appended behind it.  Block 0 has a buffer
+        # of its own whose first nf channels - the head output - are never overwritten: they are also the long skip
+        # (a channel-slice residual of the trunk conv), so the head conv runs once; blocks 1.. alternate between two.
         nb = len(m.blocks)
-        # the head output is needed twice (long skip, and x of block 0 inside the concat buffer)
+        cat = [s.buf(N, H, W, ctot), s.buf(N, H, W, ctot)] if nb > 1 else []
+        cat0 = s.buf(N, H, W, ctot) if nb else None
+        first = cat0 if nb else s.buf(N, H, W, nf)
+        first_cs = ctot if nb else 0
+        s.add((m.head, None, m.head_act), None, first, N, H, W, in_layout=L.NCHW, in_dtype=L.F32,
+              out_cstride=first_cs, out_coffset=0)
         for b, blk in enumerate(m.blocks):
-            buf = cat[b & 1]
-            if b == 0:
-                # x of block 0 = head output: produce it straight into the slice as well (same conv, second store)
-                s.add((m.head, None, m.head_act), None, buf, N, H, W, in_layout=L.NCHW, in_dtype=L.F32,
-                      out_cstride=ctot, out_coffset=0)
-                self._second_head = len(s.layers) - 1
+            buf = cat0 if b == 0 else cat[b & 1]
             for i, dc in enumerate(blk.dense):
                 s.add((dc, None, lrelu), buf, buf, N, H, W, in_cstride=ctot, out_cstride=ctot, out_coffset=nf + i * g)
             # compress: (conv + b) * 0.2 + x ; x = buf[..., :nf] (a channel slice -> res_cstride)
@@ -127,7 +126,7 @@ class RRDBPlan(_Plan):
         if not nb:
             trunk_in = first
         t = s.buf(N, H, W, nf)
-        s.add((m.trunk, None, None), trunk_in, t, N, H, W, residual=first)
+        s.add((m.trunk, None, None), trunk_in, t, N, H, W, residual=first, res_cstride=first_cs)
         x, h, w = t, H, W
         for j in range(2):
             y = s.buf(N, 2 * h, 2 * w, nf)
@@ -140,12 +139,6 @@ class RRDBPlan(_Plan):
         self.dev = dev
         self.args, self.n = s.finish()
         self.kernels, self._seq = s.kernels, s
-
-    def run(self, x):
-        x = x.contiguous().float()
-        if hasattr(self, "_second_head"):
-            self.args[self._second_head].x = x.data_ptr()
-        return super().run(x)
 
 
 class _RRDB(nn.Module):

@@ -186,6 +186,7 @@ def test_generic_kernel_bf16_storage(case):
     dict(N=1, H=9, W=20, Cout=64, act=L.ACT_PRELU, alpha_val=-0.5),           # learned slope outside [0, 1]
     dict(N=1, H=9, W=20, Cout=64, act=L.ACT_PRELU, alpha_val=1.5, residual=True),
     dict(N=1, H=9, W=20, Cout=64, act=L.ACT_LRELU, act_param=1.25),
+    dict(N=2, H=13, W=70, Cout=64, act=L.ACT_NONE, residual=True, res_cs=160),   # residual = channel slice of a concat buffer (RRDB trunk skip)
 ])
 def test_c64_bf16_kernel(case):
     name = _run_case(Cin=64, k=3, io=torch.bfloat16, compute=L.COMPUTE_BF16, **case)
