@@ -347,13 +347,16 @@ int c1_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     if (d.N == 0 || d.H == 0 || d.W == 0) return SRMI_OK;
     const int SW = 16 * (16 - d.kh + 1);
     p.strips = (d.W + SW - 1) / SW;
-    // rows per band: every band re-reads k - 1 halo rows (from L2, its neighbours stream them at the same time), so
-    // long bands are cheaper per row - but the loads in flight are what hides the HBM latency: aim at >= 8 waves per CU
+    // rows per band: every band re-reads k - 1 halo rows (through L2: its neighbours stream them at the same time), so
+    // long bands are cheaper per row, and the waves should fill the chip's 1024 SIMDs in whole rounds.  Measured at
+    // 32 x 384 x 384 (64 column strips): 12 rows = 2048 waves 82 / 182 us (32 / 64 channels), 16 rows = 1536 waves 95 / 198,
+    // 24 rows = 1024 waves 78 / 162, 48 rows = 512 waves 122 / 219: one wave per SIMD with the longer band wins.
     const long long cols = (long long)d.N * p.strips;
-    long long nbands = (2048 + cols - 1) / cols;
+    long long nbands = (1024 + cols - 1) / cols;
     int rb = (int)((d.H + nbands - 1) / nbands);
     if (rb < 8) rb = 8;
     if (rb > d.H) rb = d.H;
+    if (dbg_thin_rows() > 0) rb = dbg_thin_rows() > d.H ? d.H : dbg_thin_rows();      // (investigation: SRMI_THIN_RB)
     p.rb = rb;
     p.bands = (d.H + rb - 1) / rb;
     const long long ntask = cols * p.bands;
