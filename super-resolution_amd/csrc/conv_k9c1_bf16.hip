@@ -130,11 +130,10 @@ __global__ __launch_bounds__(256) void k9c1_kernel(K9c1Params p) {
                 const f32x2 z = decltype(MAXF)::value ? slope_act2_max(ac, s2, h2, sl2) : slope_act2(ac, s2, h2, sl2);
                 o[mt >> 1][2 * (mt & 1) + h] = pack_bf2(z[0], z[1]);
             }
-        if (x < p.W) {
-            bf16_t* dst = p.y + ((size_t)((size_t)n * p.H + y0 + k) * p.W + x) * p.out_cs + p.out_co + 64 * g + 8 * q;
-            __builtin_nontemporal_store(o[0], (u32x4*)dst);             // 4 lanes = 64 contiguous bytes of the pixel's line
-            __builtin_nontemporal_store(o[1], (u32x4*)(dst + 32));      // (plain stores: the same time within noise)
-        }
+        // whole 128-byte lines per store instruction (store_lines_x8: lanes pl and pl ^ 8 swap a half)
+        bf16_t* line = p.y + ((size_t)((size_t)n * p.H + y0 + k) * p.W + x) * p.out_cs + p.out_co + 64 * g;
+        const int xa = x0 + 16 * wave + (pl & 7);
+        store_lines_x8<true>(line, p.out_cs, pl, q, o[0], o[1], xa < p.W, xa + 8 < p.W);
     }
     };
     if (maxform) body(std::true_type{}); else body(std::false_type{});
