@@ -30,17 +30,29 @@ struct PwParams {
     const void* res; bf16_t* y;
     long long P;               // pixels (N * H * W)
     int in_cs, out_cs, out_co, res_cs, res_bf16;
+    int st16;                  // y, out_cs, out_co allow 16-byte stores (else 8-byte pieces)
     int act; float act_param; int alpha_pc;
 };
 
-// weights -> A fragments [mt][ks][lane][8]: row = 16 mt + (lane & 15), k = 32 ks + 8 (lane >> 4) + j
+// Output channel of MFMA row r of M tile mt.  A lane (pixel pl, group q) gets rows 4 q .. 4 q + 3 of every M tile; the
+// rows are permuted at pack time so that these values are CONSECUTIVE channels: 16 channels = one 8-byte store per lane
+// and 32 contiguous bytes per pixel; 32 channels = 8 q .. 8 q + 7, one 16-byte store per lane and the pixel's whole 64
+// bytes from its four lanes (a wave instruction writes 1 KB without a gap); 64 channels = 8 q .. 8 q + 7 and
+// 32 + 8 q .. + 7, two 16-byte stores of 64 contiguous bytes per pixel each.
+__host__ __device__ __forceinline__ int pw_row_to_ch(int MT, int mt, int r) {
+    if (MT == 1) return r;
+    if (MT == 2) return 8 * (r >> 2) + 4 * mt + (r & 3);
+    return 32 * (mt >> 1) + 8 * (r >> 2) + 4 * (mt & 1) + (r & 3);
+}
+
+// weights -> A fragments [mt][ks][lane][8]: row (lane & 15) of M tile mt = channel pw_row_to_ch, k = 32 ks + 8 (lane >> 4) + j
 __global__ void pw_pack_kernel(const float* __restrict__ w, bf16_t* __restrict__ out, int Cin, int Cout) {
     const int KS = Cin / 32, MT = Cout / 16;
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= MT * KS * 512) return;
     const int j = i & 7, lane = (i >> 3) & 63, f = i >> 9;
     const int ks = f % KS, mt = f / KS;
-    out[i] = f2bf(w[(size_t)(16 * mt + (lane & 15)) * Cin + 32 * ks + 8 * (lane >> 4) + j]);
+    out[i] = f2bf(w[(size_t)pw_row_to_ch(MT, mt, lane & 15) * Cin + 32 * ks + 8 * (lane >> 4) + j]);
 }
 
 template <int KS, int MT>
@@ -57,11 +69,11 @@ __global__ __launch_bounds__(256) void pw_kernel(PwParams p) {
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) a[mt][ks] = *(const bf16x8*)(p.w + ((size_t)(mt * KS + ks) * 64 + lane) * 8);
-    // this lane's output channels: 16 mt + 4 q + e
+    // this lane's output channels of M tile mt: pw_row_to_ch(MT, mt, 4 q) + e
     f32x4 sc[MT], sh[MT], sl[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-        const int c = 16 * mt + 4 * q;
+        const int c = pw_row_to_ch(MT, mt, 4 * q);
         sc[mt] = *(const f32x4*)(p.scale + c);
         sh[mt] = *(const f32x4*)(p.shift + c);
 #pragma unroll
@@ -92,9 +104,11 @@ __global__ __launch_bounds__(256) void pw_kernel(PwParams p) {
                     acc[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[mt][ks], b[u][ks], acc[mt], 0, 0, 0);
             }
             if (pix[u] < p.P) {
-                bf16_t* dst = p.y + pix[u] * p.out_cs + p.out_co + 4 * q;
+                bf16_t* dst = p.y + pix[u] * p.out_cs + p.out_co;
+                u32x2 o[MT];
 #pragma unroll
                 for (int mt = 0; mt < MT; ++mt) {
+                    const int c = pw_row_to_ch(MT, mt, 4 * q);
                     f32x4 v;
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
@@ -102,7 +116,7 @@ __global__ __launch_bounds__(256) void pw_kernel(PwParams p) {
                         v[e] = z >= 0.f ? z : z * sl[mt][e];
                     }
                     if (p.res) {                       // the residual follows the activation (srmi.h)
-                        const size_t ro = (size_t)pix[u] * p.res_cs + 16 * mt + 4 * q;
+                        const size_t ro = (size_t)pix[u] * p.res_cs + c;
                         if (p.res_bf16) {
                             const u32x2 r = *(const u32x2*)((const bf16_t*)p.res + ro);
                             v[0] += __builtin_bit_cast(float, r[0] << 16); v[1] += __builtin_bit_cast(float, r[0] & 0xffff0000u);
@@ -111,8 +125,15 @@ __global__ __launch_bounds__(256) void pw_kernel(PwParams p) {
                             v += *(const f32x4*)((const float*)p.res + ro);
                         }
                     }
-                    const u32x2 o = {pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
-                    *(u32x2*)(dst + 16 * mt) = o;
+                    o[mt] = (u32x2){pack_bf2(v[0], v[1]), pack_bf2(v[2], v[3])};
+                }
+                if constexpr (MT == 1) {
+                    *(u32x2*)(dst + 4 * q) = o[0];
+                } else {
+#pragma unroll
+                    for (int h = 0; h < MT / 2; ++h)       // channels 32 h + 8 q .. + 7: M tiles 2 h, 2 h + 1
+                        if (p.st16) *(u32x4*)(dst + 32 * h + 8 * q) = (u32x4){o[2 * h][0], o[2 * h][1], o[2 * h + 1][0], o[2 * h + 1][1]};
+                        else { *(u32x2*)(dst + 32 * h + 8 * q) = o[2 * h]; *(u32x2*)(dst + 32 * h + 8 * q + 4) = o[2 * h + 1]; }
                 }
             }
         }
@@ -158,6 +179,7 @@ int pw_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     p.P = (long long)d.N * d.H * d.W;
     p.in_cs = g.in_cs; p.out_cs = g.out_cs; p.out_co = d.out_coffset;
     p.act = d.act; p.act_param = d.act_param; p.alpha_pc = d.alpha_per_channel;
+    p.st16 = (((uintptr_t)a.y & 15) == 0 && g.out_cs % 8 == 0 && d.out_coffset % 8 == 0) ? 1 : 0;
     if (p.P == 0) return SRMI_OK;
     const int KS = d.Cin / 32, MT = d.Cout / 16;
     const int U = (KS * MT > 8) ? 2 : 4;
