@@ -92,19 +92,36 @@ def per_kernel_times(gen, x, reps):
     sr = torch.empty(plan.sr_shape, dtype=torch.float32, device=x.device)
     plan.args[n - 1].y = sr.data_ptr()
     units = plan.launches                       # (label, first conv index, convs in the launch)
+    # Runs of identical consecutive launches (the 16 fused ResBlocks) share ONE event pair: recording an event costs the
+    # GPU timeline a few microseconds (two events with nothing between them read 5 us apart), which a per-launch pair
+    # would add to every 28 us kernel; the run's time / its length is the average launch-to-launch duration.
+    def sig(u):
+        label, i, cnt = units[u]
+        d = plan.args[i].d
+        return (label, cnt, d.N, d.H, d.W, d.Cin, d.Cout, d.kh)
+    groups, u = [], 0
+    while u < len(units):
+        v = u + 1
+        while v < len(units) and sig(v) == sig(u):
+            v += 1
+        groups.append((u, v))
+        u = v
     tot = np.zeros(len(units))
     st = Fn.stream_ptr()
     for _ in range(reps):
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(units) + 1)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(groups) + 1)]
         ev[0].record()
-        for u, (label, i, cnt) in enumerate(units):
-            if cnt == 2:
-                L.check(lib.srmi_conv2d_fwd_pair(C.byref(plan.args[i]), C.byref(plan.args[i + 1]), st))
-            else:
-                L.check(lib.srmi_conv2d_fwd(C.byref(plan.args[i]), st))
-            ev[u + 1].record()
+        for gi, (u0, u1) in enumerate(groups):
+            for u in range(u0, u1):
+                label, i, cnt = units[u]
+                if cnt == 2:
+                    L.check(lib.srmi_conv2d_fwd_pair(C.byref(plan.args[i]), C.byref(plan.args[i + 1]), st))
+                else:
+                    L.check(lib.srmi_conv2d_fwd(C.byref(plan.args[i]), st))
+            ev[gi + 1].record()
         torch.cuda.synchronize()
-        tot += np.array([ev[u].elapsed_time(ev[u + 1]) for u in range(len(units))])
+        for gi, (u0, u1) in enumerate(groups):
+            tot[u0:u1] += ev[gi].elapsed_time(ev[gi + 1]) / (u1 - u0)
     return plan, units, tot / reps   # ms per launch
 
 
@@ -306,6 +323,15 @@ def main():
         achieved = flops / t_dom / 1e12
         layers = {k: {"launches": v[0], "ms": round(v[1], 4), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
                   for k, v in per_layer.items()}
+        trace_us = None      # average duration of the dominant kernel in the committed kernel trace (profiles/)
+        try:
+            import csv
+            for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r2_bench_kernel_stats.csv"))):
+                if "resblock_c64_kernel" in r["Name"] and args.compute == "bf16":
+                    trace_us = round(float(r["AverageNs"]) / 1e3, 2)
+                    break
+        except Exception:
+            trace_us = None
         traffic = None       # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_summary.py)
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))["kernels"]
@@ -316,13 +342,18 @@ def main():
                     "launches_per_step": n_dom, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
                     "avg_launch_us": round(t_dom / n_dom * 1e6, 2),
+                    # average kernel duration in the committed rocprofv3 kernel trace of this command (kernels of consecutive
+                    # launches overlap by ~2 us there: the next one's waves start while the previous one's stores drain)
+                    "kernel_trace_avg_us": trace_us,
+                    "frac_by_kernel_trace": round(flops / n_dom / (trace_us * 1e-6) / 1e12 / peak, 4) if trace_us else None,
                     "flops_per_launch": flops / n_dom,
                     "algorithmic_bytes_per_launch": 2 * BATCH * LR_H * LR_W * 64 * 2,
                     "mfma_family_tflops": round(f_fam / t_fam / 1e12, 2),
                     "whole_step_frac": round(value / world * 1e6 * FLOP_PER_OUT_PIXEL / 1e12 / peak, 4),
                     "sum_kernel_ms": round(float(kms.sum()), 4), "layers": layers,
                     "hbm_bound_layers": hbm_bound_layers(plan, units, kms, gen, x),
-                    "method": "HIP events (torch's current stream = the launch stream) around every launch of "
+                    "method": "HIP events (torch's current stream = the launch stream) around every launch (one pair around each run of "
+                              "identical consecutive launches, e.g. the 16 ResBlocks: time / run length) of "
                               "instrumented forwards run right after the timed region, same process/data; achieved = "
                               "algorithmic conv FLOPs of the kernel's launches / their event time; traffic = FETCH_SIZE x2 "
                               "+ WRITE_SIZE per launch from separate rocprofv3 --pmc passes (profiles/r2_pmc_traffic.json)"}
