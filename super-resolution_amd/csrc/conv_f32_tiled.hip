@@ -239,8 +239,8 @@ static long long f32t_wgs(const GenericParams& p, int c) {
 void f32t_plan(const GenericParams& p, bool allow_split, int* cfg, int* ks) {
     const int BK = p.Cin_pad <= 8 ? 8 : (p.Cin_pad >= 32 ? 32 : 16);
     const int KC = p.kh * p.kw * ((p.Cin_pad + BK - 1) / BK);
-    const bool linear = !(p.scale || p.act != SRMI_ACT_NONE || p.res || p.out_bf16 || p.r != 1) &&
-                        (p.out_nchw || p.out_cs == p.Cf);
+    const bool linear = (!(p.scale || p.act != SRMI_ACT_NONE || p.res || p.out_bf16 || p.r != 1) &&
+                         (p.out_nchw || p.out_cs == p.Cf)) || generic_subpix2_shape(p);
     *ks = 1;
     if (p.Cout <= 32) {
         *cfg = f32t_wgs(p, 2) >= 512 ? 2 : 4;

@@ -66,6 +66,39 @@ __device__ __forceinline__ void generic_epilogue_flat(const GenericParams& p, co
     }
 }
 
+// Lean epilogue of the stride-2 dgrad in its sub-pixel form (conv_generic.hip: dgrad_subpixel): raw f32 sums stored
+// through depth_to_space(2), NHWC.  Cf % 32 == 0, so a 32-channel tile lies inside ONE sub-pixel (si, sj) and the 32 lanes
+// of a row write 128 contiguous bytes; the output pixel of each accumulator row comes from one cross-lane read of the
+// owning lane's base pixel, shared by all channel tiles (the general epilogue below does three per element and tile).
+// (the shape it serves; such a launch may also split K: the slices go to p.partial with the same indexing)
+__host__ __device__ __forceinline__ bool generic_subpix2_shape(const GenericParams& p) {
+    return p.r == 2 && p.dcr && !p.out_nchw && p.act == SRMI_ACT_NONE && !p.scale && !p.shift && !p.res && !p.out_bf16 &&
+           p.Cf % 32 == 0 && p.Cout == 4 * p.Cf && p.out_cs == p.Cf && p.out_co == 0;
+}
+
+template <int NT>
+__device__ __forceinline__ void generic_epilogue_subpix2(const GenericParams& p, const f32x16 (&acc)[NT], int m0, int co0,
+                                                         int n, int oy, int ox, int lane, int zslice) {
+    const int i = lane & 31, h = lane >> 5;
+    const int base = (n * p.Hf + 2 * oy) * p.Wf + 2 * ox;        // sub-pixel (0, 0) of pixel m0 + i (fits int: checked on the host)
+    int rowpx[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) rowpx[e] = __shfl(base, (e & 3) + 8 * (e >> 2) + 4 * h);
+    float* y = p.ksplit > 1 ? p.partial + (size_t)zslice * p.partial_stride : (float*)p.y;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+        const int cot = co0 + 32 * t;                            // wave-uniform
+        if (cot >= p.Cout) continue;
+        const int sub = cot / p.Cf, c = cot - sub * p.Cf + i;
+        const int shift = (sub >> 1) * p.Wf + (sub & 1);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (m0 + row < p.M) y[(size_t)(rowpx[e] + shift) * p.out_cs + p.out_co + c] = acc[t][e];
+        }
+    }
+}
+
 // Fused epilogue of NT 32(pixel) x 32(channel) accumulator tiles of v_mfma_f32_32x32x2_f32:
 //   scale/shift -> act -> +residual -> (sub-pixel) store, or the raw slice of a split-K launch.
 // acc[t][e] = pixel row (e&3) + 8*(e>>2) + 4*h of the tile starting at flattened output pixel m0, channel co0 + 32*t + i
@@ -73,6 +106,10 @@ __device__ __forceinline__ void generic_epilogue_flat(const GenericParams& p, co
 template <int NT>
 __device__ __forceinline__ void generic_epilogue(const GenericParams& p, const f32x16 (&acc)[NT], int m0, int co0, int n,
                                                  int oy, int ox, int lane, int zslice) {
+    if (generic_subpix2_shape(p)) {
+        generic_epilogue_subpix2<NT>(p, acc, m0, co0, n, oy, ox, lane, zslice);
+        return;
+    }
     if (p.r == 1 && !p.out_nchw && p.act != SRMI_ACT_TANH && p.act != SRMI_ACT_SIGMOID && p.act != SRMI_ACT_ADD_RELU) {
         if (p.ksplit > 1) generic_epilogue_flat<NT, false, false, false, true>(p, acc, m0, co0, lane, zslice);
         else if (!p.res) {
