@@ -467,7 +467,7 @@ int srmi_y_psnr_ssim_batch(const float* sr, const float* gt, int32_t n_images, i
 
 static int epi_check(const char* what, const srmi_epi_desc* d) {
     if (!d) { set_error("%s: NULL descriptor", what); return SRMI_EINVAL; }
-    if (d->N < 0 || d->H < 0 || d->W < 0 || d->C <= 0 || d->shuffle < 1 || d->C % (d->shuffle * d->shuffle) != 0 ||
+    if (d->N < 0 || d->H < 0 || d->W < 0 || d->C <= 0 || d->C > (1 << 22) || d->shuffle < 1 || d->C % (d->shuffle * d->shuffle) != 0 ||
         d->act < SRMI_ACT_NONE || d->act > SRMI_ACT_SIGMOID ||
         (d->shuffle_order != SRMI_SHUFFLE_CRD && d->shuffle_order != SRMI_SHUFFLE_DCR)) {
         set_error("%s: bad descriptor N=%d H=%d W=%d C=%d r=%d act=%d", what, d->N, d->H, d->W, d->C, d->shuffle, d->act);

@@ -24,7 +24,19 @@
 namespace srmi {
 
 // BK: channels per chunk (16; 8 for Cin <= 8).  WM x WN waves (= 4), each TM x TN tiles of 32 x 32.
-template <int BK, int WM, int WN, int TM, int TN>
+//
+// FAST (chosen on the host, f32t_fast): 16-byte activation loads, Cin a multiple of BK, no strided transposed taps, no
+// ablation switches.  The chunk loop then has no per-element channel checks, no scalar-load fallback and no run-time
+// divisions (tap and channel offset advance incrementally), which keeps its scalar state in registers: the general
+// variant re-reads its kernel arguments from memory several times per chunk.
+__device__ __forceinline__ int fastdiv(int n, unsigned mul, int sh) {      // n / d for 0 <= n < 2^31 (f32t_magic)
+    return (int)(((unsigned long long)(unsigned)n * mul) >> sh);
+}
+
+// bits lo..hi of a 32-bit mask (empty when hi < lo; hi <= 31)
+__device__ __forceinline__ unsigned bit_range(int lo, int hi) { return hi >= lo ? (2u << hi) - (1u << lo) : 0u; }
+
+template <int BK, int WM, int WN, int TM, int TN, bool FAST>
 __global__ __launch_bounds__(256) void conv_f32t_kernel(GenericParams p) {
     static_assert(WM * WN == 4, "four waves per workgroup");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
@@ -68,31 +80,27 @@ __global__ __launch_bounds__(256) void conv_f32t_kernel(GenericParams p) {
         const int m = m0 + idx / NPIECE;
         a_img[l] = 0; a_base[l] = 0; a_rm[l] = 0u; a_cm[l] = 0u;
         if (idx < A_TOTAL && m < p.M) {
-            // (integer division costs ~40 instructions per lane on this ISA: two per load here, none per tap)
-            const int tq = m / p.Wo;
+            // (a run-time integer division costs ~40 instructions per lane on this ISA: multiply-shift with host-made
+            // constants instead)
+            const int tq = fastdiv(m, p.wo_mul, p.wo_sh);
             const int ox = m - tq * p.Wo;
-            const int n = tq / p.Ho;
+            const int n = fastdiv(tq, p.ho_mul, p.ho_sh);
             const int oy = tq - n * p.Ho;
             a_img[l] = n * p.H * p.W;
             const int by = p.transposed ? oy + p.pad : oy * p.stride - p.pad;
             const int bx = p.transposed ? ox + p.pad : ox * p.stride - p.pad;
             a_base[l] = by * p.W + bx;
             auto axis_mask = [&](int b, int taps, int extent) {
+                if (!p.transposed) return bit_range(max(0, -b), min(taps - 1, extent - 1 - b));     // 0 <= b + k < extent
+                if (FAST || p.stride == 1) return bit_range(max(0, b - extent + 1), min(taps - 1, b));   // 0 <= b - k < extent
                 unsigned mk = 0u;
-                for (int k = 0; k < taps; ++k) {
-                    bool v;
-                    if (p.transposed) {
-                        const int tcoord = b - k;
-                        int ic = tcoord;
-                        v = tcoord >= 0;
-                        if (p.stride == 2) { v = v && !(tcoord & 1); ic = tcoord >> 1; }
-                        else if (p.stride > 2) { v = v && tcoord % p.stride == 0; ic = tcoord / p.stride; }
-                        v = v && ic < extent;
-                    } else {
-                        const int ic = b + k;
-                        v = ic >= 0 && ic < extent;
-                    }
-                    if (v) mk |= 1u << k;
+                for (int k = 0; k < taps; ++k) {             // strided transposed taps: (b - k) divisible by the stride
+                    const int tcoord = b - k;
+                    bool v = tcoord >= 0;
+                    int ic;
+                    if (p.stride == 2) { v = v && !(tcoord & 1); ic = tcoord >> 1; }
+                    else { v = v && tcoord % p.stride == 0; ic = tcoord / p.stride; }
+                    if (v && ic < extent) mk |= 1u << k;
                 }
                 return mk;
             };
@@ -103,7 +111,50 @@ __global__ __launch_bounds__(256) void conv_f32t_kernel(GenericParams p) {
     const float* xf = (const float*)p.x;
     f32x4 ra[A_LOADS], rb[B_LOADS];
 
+    // FAST: (tap row, tap column, first channel) of the NEXT chunk to load; chunks are loaded in order, so the state
+    // advances by BK channels per call instead of dividing the chunk index
+    int nx_ky = 0, nx_kx = 0, nx_c0 = 0;
+    if constexpr (FAST) {
+        const int tap0 = kc0 / cpt;
+        nx_c0 = (kc0 - tap0 * cpt) * BK;
+        nx_ky = tap0 / p.kw;
+        nx_kx = tap0 - nx_ky * p.kw;
+    }
+    const int in_cs = p.in_cs, Wi = p.W;
+    const size_t w_tap = (size_t)p.Cin_pad * p.Cout_pad;
+    const int b_row = tid / (BN / 4), b_c4 = tid % (BN / 4);         // weight slab piece of load 0 (256 / (BN/4) rows per load)
+    const bool b_ok = co0 + 4 * b_c4 < p.Cout_pad;
+
     auto load_chunk = [&](int c) {
+        if constexpr (FAST) {
+            const int ky = nx_ky, kx = nx_kx, c0 = nx_c0;
+            const int tapoff = ky * Wi + kx;
+#pragma unroll
+            for (int l = 0; l < A_LOADS; ++l) {
+                const int idx = tid + 256 * l;
+                const bool v = ((a_rm[l] >> ky) & (a_cm[l] >> kx) & 1u) != 0u;
+                f32x4 q = {0.f, 0.f, 0.f, 0.f};
+                if (v) {
+                    const int pix = p.transposed ? a_base[l] - tapoff : a_base[l] + tapoff;
+                    q = *(const f32x4*)(xf + (size_t)(a_img[l] + pix) * in_cs + c0 + 4 * (idx % NPIECE));
+                }
+                ra[l] = q;
+            }
+            const float* wsrc = p.w + (size_t)(ky * p.kw + kx) * w_tap + (size_t)c0 * p.Cout_pad + co0 + 4 * b_c4;
+#pragma unroll
+            for (int l = 0; l < B_LOADS; ++l) {
+                const int row = b_row + l * (256 / (BN / 4));
+                f32x4 q = {0.f, 0.f, 0.f, 0.f};
+                if (b_ok && (B_TOTAL % 256 == 0 || row < BK)) q = *(const f32x4*)(wsrc + (size_t)row * p.Cout_pad);
+                rb[l] = q;
+            }
+            nx_c0 += BK;
+            if (nx_c0 >= p.Cin_pad) {
+                nx_c0 = 0;
+                if (++nx_kx == p.kw) { nx_kx = 0; ++nx_ky; }
+            }
+            return;
+        }
         const int tap = c / cpt;                         // scalar
         const int c0 = (c - tap * cpt) * BK;
         const int ky = tap / p.kw, kx = tap - ky * p.kw;
@@ -172,8 +223,8 @@ __global__ __launch_bounds__(256) void conv_f32t_kernel(GenericParams p) {
     int buf = 0;
     for (int c = kc0; c < kc1; ++c) {
         const bool more = c + 1 < kc1;
-        if (more && !(p.dbg & (1 << 26))) load_chunk(c + 1);                    // in flight under the MFMAs below
-        if (!(p.dbg & (1 << 28)))
+        if (more && (FAST || !(p.dbg & (1 << 26)))) load_chunk(c + 1);          // in flight under the MFMAs below
+        if (FAST || !(p.dbg & (1 << 28)))
 #pragma unroll
         for (int kk = 0; kk < BK / 2; ++kk) {
             const int k = 2 * kk + h;
@@ -189,8 +240,8 @@ __global__ __launch_bounds__(256) void conv_f32t_kernel(GenericParams p) {
                 for (int b = 0; b < TN; ++b)
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b], 0, 0, 0);
         }
-        if (more && !(p.dbg & (1 << 27))) store_chunk(buf ^ 1);
-        if (!(p.dbg & (1 << 29))) __syncthreads();
+        if (more && (FAST || !(p.dbg & (1 << 27)))) store_chunk(buf ^ 1);
+        if (FAST || !(p.dbg & (1 << 29))) __syncthreads();
         buf ^= 1;
     }
 
@@ -203,12 +254,12 @@ __global__ __launch_bounds__(256) void conv_f32t_kernel(GenericParams p) {
         int n = 0, oy = 0, ox = 0;
         if (p.r != 1 || p.out_nchw) {                    // (the dense NHWC store needs no pixel coordinates)
             const int m = max(0, min(mt + i, p.M - 1));
-            const int tq = m / p.Wo;
+            const int tq = fastdiv(m, p.wo_mul, p.wo_sh);
             ox = m - tq * p.Wo;
-            n = tq / p.Ho;
+            n = fastdiv(tq, p.ho_mul, p.ho_sh);
             oy = tq - n * p.Ho;
         }
-        if (!(p.dbg & (1 << 30))) generic_epilogue<TN>(p, acc[a], mt, co0 + wn * TN * 32, n, oy, ox, lane, blockIdx.z);
+        if (FAST || !(p.dbg & (1 << 30))) generic_epilogue<TN>(p, acc[a], mt, co0 + wn * TN * 32, n, oy, ox, lane, blockIdx.z);
     };
     epi(std::integral_constant<int, 0>{});
     if constexpr (TM > 1) epi(std::integral_constant<int, 1>{});
@@ -232,12 +283,18 @@ bool f32t_supported(const GenericParams& p) {
 // else the smallest tile.
 static const int kBM[5] = {128, 128, 256, 64, 128}, kBN[5] = {128, 64, 32, 64, 32};
 
+static int f32t_bk(const GenericParams& p) {
+    if (dbg_flags() & (1 << 10)) return p.Cin_pad <= 8 ? 8 : 16;   // experiment: half-size chunks, twice the workgroups per CU
+    return p.Cin_pad <= 8 ? 8 : (p.Cin_pad >= 32 ? 32 : 16);
+}
+
 static long long f32t_wgs(const GenericParams& p, int c) {
     return (long long)((p.M + kBM[c] - 1) / kBM[c]) * ((p.Cout + kBN[c] - 1) / kBN[c]);
 }
 
 void f32t_plan(const GenericParams& p, bool allow_split, int* cfg, int* ks) {
-    const int BK = p.Cin_pad <= 8 ? 8 : (p.Cin_pad >= 32 ? 32 : 16);
+    if (dbg_flags() & (1 << 11)) allow_split = false;     // experiment: never split K
+    const int BK = f32t_bk(p);
     const int KC = p.kh * p.kw * ((p.Cin_pad + BK - 1) / BK);
     const bool linear = (!(p.scale || p.act != SRMI_ACT_NONE || p.res || p.out_bf16 || p.r != 1) &&
                          (p.out_nchw || p.out_cs == p.Cf)) || generic_subpix2_shape(p);
@@ -270,15 +327,38 @@ int f32t_ksplit(const GenericParams& p) {
     return ks;
 }
 
-int f32t_launch(const GenericParams& p) {
+// multiply-shift constants of n / d for 0 <= n < 2^31, d >= 1: s = ceil(log2 d), mul = floor(2^(31+s) / d) + 1 (< 2^32),
+// n / d = (n * mul) >> (31 + s)  (error term n * e / (d * 2^(31+s)) < 1 / d for e <= d <= 2^s)
+static void f32t_magic(int d, unsigned* mul, int* sh) {
+    int s = 0;
+    while ((1LL << s) < d) ++s;
+    *mul = (unsigned)(((1ULL << (31 + s)) / (unsigned long long)d) + 1ULL);
+    *sh = 31 + s;
+}
+
+// the lean chunk loop's preconditions (see the kernel)
+static bool f32t_fast(const GenericParams& p, int BK) {
+    return p.vec_ok && p.Cin % BK == 0 && p.Cin_pad == p.Cin && !(p.transposed && p.stride > 1) && p.dbg == 0 &&
+           p.in_cs % 4 == 0;
+}
+
+int f32t_launch(const GenericParams& p0) {
+    GenericParams p = p0;
     int c, ks;
-    const_cast<GenericParams&>(p).dbg = dbg_flags();
+    p.dbg = dbg_flags();
     f32t_plan(p, p.ksplit > 1, &c, &ks);                 // p.ksplit was fixed by generic_run (1 when there is no workspace)
+    f32t_magic(p.Wo > 0 ? p.Wo : 1, &p.wo_mul, &p.wo_sh);
+    f32t_magic(p.Ho > 0 ? p.Ho : 1, &p.ho_mul, &p.ho_sh);
     const int BM = kBM[c], BN = kBN[c];
-    const int BK = p.Cin_pad <= 8 ? 8 : (p.Cin_pad >= 32 ? 32 : 16);
+    const int BK = f32t_bk(p);
+    const bool fast = f32t_fast(p, BK);
     dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.Cout + BN - 1) / BN), (unsigned)p.ksplit);
     hipStream_t s = p.stream;
-#define SRMI_F32T(BKv, a, b, c_, d_) hipLaunchKernelGGL((conv_f32t_kernel<BKv, a, b, c_, d_>), grid, dim3(256), 0, s, p)
+#define SRMI_F32T(BKv, a, b, c_, d_)                                                                      \
+    do {                                                                                                  \
+        if (fast) hipLaunchKernelGGL((conv_f32t_kernel<BKv, a, b, c_, d_, true>), grid, dim3(256), 0, s, p);   \
+        else hipLaunchKernelGGL((conv_f32t_kernel<BKv, a, b, c_, d_, false>), grid, dim3(256), 0, s, p);       \
+    } while (0)
 #define SRMI_F32T_CFG(BKv)                              \
     switch (c) {                                        \
         case 0: SRMI_F32T(BKv, 2, 2, 2, 2); break;      \

@@ -19,6 +19,7 @@ struct GenericParams {
     size_t partial_stride;  // as y) and generic_splitk_reduce_kernel adds the slices in index order: deterministic
     int transposed;  // dgrad: gather dz at (o + pad - k) / stride where divisible
     int dbg;         // ablation switches of the tiled kernel (SRMI_DBG bits 26..29; investigation only, 0 = product path)
+    unsigned wo_mul, ho_mul; int wo_sh, ho_sh;   // tiled kernel: multiply-shift division by Wo / Ho (f32t_magic)
 };
 
 

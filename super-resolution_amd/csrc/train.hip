@@ -6,12 +6,14 @@
 // pixels and an LDS tree across the waves; every workgroup then STORES its f64 partial sums in its own slot of the
 // caller's workspace and a finalize launch adds the slots in index order.  No atomics: the same input gives the
 // same bits on every run (tests/test_srgan_step_gpu.py::test_srgan_step_is_bit_reproducible).
+#include <initializer_list>
+
 #include "common.h"
 
 namespace srmi {
 
 constexpr int CH_BLOCK = 256;
-constexpr int TRAIN_MAX_SLOTS = 128;      // partial slots per channel in the workspace (srmi_train_workspace_bytes)
+constexpr int TRAIN_MAX_SLOTS = 512;      // most partial slots per channel in the workspace (srmi_train_workspace_bytes)
 
 struct EpiParams {
     const float* z; const float* dy; const float* mean; const float* rstd; const float* gamma; const float* beta;
@@ -68,19 +70,56 @@ __global__ __launch_bounds__(CH_BLOCK) void bn_stats_kernel(const float* __restr
     }
 }
 
-// mean, 1/sqrt(var+eps) and the running-statistics update of nn.BatchNorm2d (momentum, unbiased running var)
-// sum of the partial slots of channel c, array k of KA: 8 threads per channel take the slots g, g + 8, ... in order and
-// the 8 sub-sums are added in g order (a fixed association: deterministic).  Block = 32 channels x 8 groups.
+// The same sums for C % 4 == 0 (every layer of the SRGAN step): a lane owns FOUR channels (one 16-byte load per pixel),
+// 16 lanes cover a 64-channel group, 16 pixel rows per workgroup pass; the 16 rows meet in LDS and are added in row
+// order.  A wave instruction reads 4 whole pixels of 256 bytes instead of one 4-byte element per lane.
+__device__ __forceinline__ void rows16_reduce(double (&t)[4], double (*sh)[64], int prow, int l16) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sh[prow][4 * l16 + j] = t[j];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(CH_BLOCK) void bn_stats_v4_kernel(const float* __restrict__ z, long long M, int C,
+                                                               double* __restrict__ acc) {
+    __shared__ double l1[16][64], l2[16][64];
+    const int l16 = threadIdx.x & 15, prow = threadIdx.x >> 4;
+    const int c0 = blockIdx.y * 64 + 4 * l16;
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0};
+    if (c0 < C) {
+#pragma unroll 4
+        for (long long m = (long long)blockIdx.x * 16 + prow; m < M; m += (long long)gridDim.x * 16) {
+            const f32x4 v = *(const f32x4*)(z + (size_t)m * C + c0);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const double d = (double)v[j]; s1[j] += d; s2[j] += d * d; }
+        }
+    }
+    rows16_reduce(s1, l1, prow, l16);
+    rows16_reduce(s2, l2, prow, l16);
+    const int c = blockIdx.y * 64 + threadIdx.x;
+    if (threadIdx.x < 64 && c < C) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { a += l1[r][threadIdx.x]; b += l2[r][threadIdx.x]; }
+        acc[((size_t)blockIdx.x * 2) * C + c] = a;
+        acc[((size_t)blockIdx.x * 2 + 1) * C + c] = b;
+    }
+}
+
+// sum of the partial slots of channel c, array k of KA: 32 threads per channel take the slots g, g + 32, ... in order
+// and the 32 sub-sums are added in g order (a fixed association: deterministic).  Block = 8 channels x 32 groups.
+constexpr int FIN_CH = 8, FIN_G = 32;
 template <int KA>
 __device__ __forceinline__ void slot_sums(const double* __restrict__ acc, int nslots, int C, int c, int g, double (&t)[KA],
-                                          double (*sh)[8][32]) {
+                                          double (*sh)[FIN_G][FIN_CH]) {
 #pragma unroll
     for (int k = 0; k < KA; ++k) t[k] = 0.0;
-    if (c < C)
-        for (int b = g; b < nslots; b += 8)
+    if (c < C) {
+#pragma unroll 4
+        for (int b = g; b < nslots; b += FIN_G)
 #pragma unroll
             for (int k = 0; k < KA; ++k) t[k] += acc[((size_t)b * KA + k) * C + c];
-    const int cl = threadIdx.x & 31;
+    }
+    const int cl = threadIdx.x % FIN_CH;
 #pragma unroll
     for (int k = 0; k < KA; ++k) sh[k][g][cl] = t[k];
     __syncthreads();
@@ -88,17 +127,18 @@ __device__ __forceinline__ void slot_sums(const double* __restrict__ acc, int ns
     for (int k = 0; k < KA; ++k) {
         double a = 0.0;
 #pragma unroll
-        for (int r = 0; r < 8; ++r) a += sh[k][r][cl];
+        for (int r = 0; r < FIN_G; ++r) a += sh[k][r][cl];
         t[k] = a;
     }
 }
 
+// mean, 1/sqrt(var+eps) and the running-statistics update of nn.BatchNorm2d (momentum, unbiased running var)
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ acc, int nslots, long long M, int C,
                                                           float eps, float momentum, float* __restrict__ mean,
                                                           float* __restrict__ rstd, float* __restrict__ rmean,
                                                           float* __restrict__ rvar) {
-    __shared__ double sh[2][8][32];
-    const int c = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+    __shared__ double sh[2][FIN_G][FIN_CH];
+    const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH, g = threadIdx.x / FIN_CH;
     double t[2];
     slot_sums<2>(acc, nslots, C, c, g, t, sh);
     if (c >= C || g != 0) return;
@@ -129,6 +169,33 @@ __global__ __launch_bounds__(CH_BLOCK) void epilogue_fwd_kernel(EpiParams p) {
         v = apply_act(v, p.act, p.act_param, al);
         if (p.residual) v += p.residual[o];
         p.y[o] = v;
+    }
+}
+
+// r == 1 and C / 4 dividing the workgroup size: a lane keeps the same four channels for the whole grid-stride loop (its
+// per-channel constants are loaded once, no index division) and moves 16 bytes per access.  Same arithmetic, same bits.
+__global__ __launch_bounds__(CH_BLOCK) void epilogue_fwd_v4_kernel(EpiParams p) {
+    const size_t total4 = (size_t)p.M * p.C / 4;
+    const int c0 = 4 * (int)(threadIdx.x % (unsigned)(p.C / 4));
+    f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = mu, ga = mu, be = mu, al = mu;
+    if (p.bn) { mu = *(const f32x4*)(p.mean + c0); rs = *(const f32x4*)(p.rstd + c0); ga = *(const f32x4*)(p.gamma + c0); be = *(const f32x4*)(p.beta + c0); }
+    if (p.act == SRMI_ACT_PRELU) {
+        if (p.alpha_pc) al = *(const f32x4*)(p.alpha + c0);
+        else { const float a0 = p.alpha[0]; al = f32x4{a0, a0, a0, a0}; }
+    }
+    for (size_t i = (size_t)blockIdx.x * CH_BLOCK + threadIdx.x; i < total4; i += (size_t)gridDim.x * CH_BLOCK) {
+        f32x4 v = *(const f32x4*)(p.z + 4 * i);
+        f32x4 rsd = {0.f, 0.f, 0.f, 0.f};
+        if (p.residual) rsd = *(const f32x4*)(p.residual + 4 * i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float u = v[j];
+            if (p.bn) u = (u - mu[j]) * rs[j] * ga[j] + be[j];
+            u = apply_act(u, p.act, p.act_param, al[j]);
+            if (p.residual) u += rsd[j];
+            v[j] = u;
+        }
+        *(f32x4*)(p.y + 4 * i) = v;
     }
 }
 
@@ -176,7 +243,84 @@ __global__ __launch_bounds__(CH_BLOCK) void epilogue_bwd_kernel(EpiParams p) {
     }
 }
 
+// pass 1 for r == 1, C % 4 == 0: four channels per lane, 16 pixel rows per workgroup pass (see bn_stats_v4_kernel)
+__global__ __launch_bounds__(CH_BLOCK) void epilogue_bwd_v4_kernel(EpiParams p) {
+    __shared__ double l1[16][64], l2[16][64], l3[16][64];
+    const int l16 = threadIdx.x & 15, prow = threadIdx.x >> 4;
+    const int c0 = blockIdx.y * 64 + 4 * l16;
+    double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0}, s3[4] = {0.0, 0.0, 0.0, 0.0};
+    if (c0 < p.C) {
+        f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = {1.f, 1.f, 1.f, 1.f}, ga = rs, be = mu, sl = mu;
+        if (p.bn) { mu = *(const f32x4*)(p.mean + c0); rs = *(const f32x4*)(p.rstd + c0); ga = *(const f32x4*)(p.gamma + c0); be = *(const f32x4*)(p.beta + c0); }
+        if (p.act == SRMI_ACT_PRELU || p.act == SRMI_ACT_LRELU || p.act == SRMI_ACT_RELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) sl[j] = slope_of(p, c0 + j);
+        }
+        const int M = (int)p.M;
+#pragma unroll 2
+        for (int m = blockIdx.x * 16 + prow; m < M; m += gridDim.x * 16) {
+            const size_t idx = (size_t)m * p.C + c0;
+            const f32x4 zv = *(const f32x4*)(p.z + idx);
+            const f32x4 gv = *(const f32x4*)(p.dy + idx);
+            f32x4 out;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float zh = (zv[j] - mu[j]) * rs[j];        // = z when !bn
+                const float u = p.bn ? zh * ga[j] + be[j] : zh;
+                const float g0 = gv[j];
+                float g;
+                switch (p.act) {
+                    case SRMI_ACT_PRELU: case SRMI_ACT_LRELU: case SRMI_ACT_RELU: {
+                        g = u > 0.f ? g0 : g0 * sl[j];
+                        if (p.act == SRMI_ACT_PRELU && !(u > 0.f)) s3[j] += (double)g0 * (double)u;
+                        break;
+                    }
+                    case SRMI_ACT_TANH: { const float t = tanhf(u); g = g0 * (1.f - t * t); break; }
+                    case SRMI_ACT_SIGMOID: { const float sg = 1.f / (1.f + expf(-u)); g = g0 * sg * (1.f - sg); break; }
+                    default: g = g0;
+                }
+                out[j] = g;
+                s1[j] += (double)g;
+                s2[j] += (double)g * (double)zh;
+            }
+            *(f32x4*)(p.dz + idx) = out;
+        }
+    }
+    rows16_reduce(s1, l1, prow, l16);
+    rows16_reduce(s2, l2, prow, l16);
+    rows16_reduce(s3, l3, prow, l16);
+    const int c = blockIdx.y * 64 + threadIdx.x;
+    if (threadIdx.x < 64 && c < p.C) {
+        double a = 0.0, b = 0.0, d = 0.0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { a += l1[r][threadIdx.x]; b += l2[r][threadIdx.x]; d += l3[r][threadIdx.x]; }
+        double* slot = p.acc + (size_t)blockIdx.x * 3 * p.C;
+        slot[c] = a; slot[p.C + c] = b; slot[2 * p.C + c] = d;
+    }
+}
+
 // pass 2 (BN only): dz = gamma * rstd * (g - S1/M - zhat * S2/M)
+__global__ __launch_bounds__(CH_BLOCK) void bn_bwd_apply_v4_kernel(EpiParams p) {
+    const size_t total4 = (size_t)p.M * p.C / 4;
+    const double invM = 1.0 / (double)p.M;
+    const int c0 = 4 * (int)(threadIdx.x % (unsigned)(p.C / 4));
+    const double* tot = p.acc + (size_t)p.nslots * 3 * p.C;           // totals, written by the finalize launch
+    const f32x4 mu = *(const f32x4*)(p.mean + c0), rs = *(const f32x4*)(p.rstd + c0), ga = *(const f32x4*)(p.gamma + c0);
+    f32x4 m1, m2;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { m1[j] = (float)(tot[c0 + j] * invM); m2[j] = (float)(tot[p.C + c0 + j] * invM); }
+    for (size_t i = (size_t)blockIdx.x * CH_BLOCK + threadIdx.x; i < total4; i += (size_t)gridDim.x * CH_BLOCK) {
+        const f32x4 zv = *(const f32x4*)(p.z + 4 * i);
+        f32x4 g = *(const f32x4*)(p.dz + 4 * i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float zh = (zv[j] - mu[j]) * rs[j];
+            g[j] = ga[j] * rs[j] * (g[j] - m1[j] - zh * m2[j]);
+        }
+        *(f32x4*)(p.dz + 4 * i) = g;
+    }
+}
+
 __global__ __launch_bounds__(CH_BLOCK) void bn_bwd_apply_kernel(EpiParams p) {
     const size_t total = (size_t)p.M * p.C;
     const double invM = 1.0 / (double)p.M;
@@ -191,7 +335,7 @@ __global__ __launch_bounds__(CH_BLOCK) void bn_bwd_apply_kernel(EpiParams p) {
 }
 
 // partial slots -> totals (kept for bn_bwd_apply_kernel) and f32 parameter gradients, all sums in a fixed order.
-// Workgroups 0 .. ceil(C/32)-1: 32 channels each (slot_sums).  The LAST workgroup produces dalpha from the slots:
+// Workgroups 0 .. ceil(C/8)-1: 8 channels each (slot_sums).  The LAST workgroup produces dalpha from the slots:
 // per-channel slopes (n_alpha = Cf): thread cf adds the conv channels that store to final channel cf, slot by slot;
 // one shared slope (n_alpha = 1): 256 threads each add a strided share of the channels in order, then thread 0 adds
 // the 256 shares in order.
@@ -199,11 +343,11 @@ __global__ __launch_bounds__(256) void epilogue_bwd_finalize_kernel(double* __re
                                                                     int n_alpha, int bn, int Cf, int rr, int dcr,
                                                                     float* __restrict__ dsum1, float* __restrict__ dsum2,
                                                                     float* __restrict__ dalpha) {
-    __shared__ double sh3[3][8][32];
+    __shared__ double sh3[3][FIN_G][FIN_CH];
     __shared__ double sh[256];
     double* tot = acc + (size_t)nslots * 3 * C;
     if (blockIdx.x + 1 < gridDim.x) {
-        const int c = blockIdx.x * 32 + (threadIdx.x & 31), g = threadIdx.x >> 5;
+        const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH, g = threadIdx.x / FIN_CH;
         double t[3];
         slot_sums<3>(acc, nslots, C, c, g, t, sh3);
         if (c >= C || g != 0) return;
@@ -225,15 +369,25 @@ __global__ __launch_bounds__(256) void epilogue_bwd_finalize_kernel(double* __re
         return;
     }
     double t = 0.0;
-    for (long long it = threadIdx.x; it < (long long)nslots * C; it += 256) {      // item = (slot, channel), fixed order per thread
-        const int b = (int)(it / C), c = (int)(it - (long long)b * C);
+    const int items = nslots * C;                  // <= 512 slots x C: 32-bit (C < 2^22 is checked on the host)
+#pragma unroll 4
+    for (int it = threadIdx.x; it < items; it += 256) {      // item = (slot, channel), fixed order per thread
+        const int b = it / C, c = it - b * C;
         t += acc[(size_t)b * 3 * C + 2 * C + c];
     }
     sh[threadIdx.x] = t;
     __syncthreads();
+    if (threadIdx.x < 16) {                        // 16 threads add 16 shares each in order, thread 0 the 16 results
+        double a = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += sh[threadIdx.x * 16 + k];
+        sh[threadIdx.x * 16] = a;
+    }
+    __syncthreads();
     if (threadIdx.x == 0) {
         double a = 0.0;
-        for (int k = 0; k < 256; ++k) a += sh[k];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) a += sh[k * 16];
         dalpha[0] = (float)a;
     }
 }
@@ -347,27 +501,43 @@ static unsigned ew_blocks(size_t total) {
     return (unsigned)b;
 }
 
-// grid of the per-channel reductions: x = pixel slices (each leaves one partial slot: at most TRAIN_MAX_SLOTS),
-// y = 64-channel groups; ~1024 workgroups in total
-static dim3 ch_grid(long long M, int C) {
-    long long bx = (M + 63) / 64;  // >= 16 pixels per wave
-    long long cap = 1024 / ((C + 63) / 64);
+// grid of the per-channel reductions: x = pixel slices (each leaves one partial slot: at most max_slots(C)),
+// y = 64-channel groups; ~1024 workgroups in total (four per CU: the loops are latency-bound streams)
+static int max_slots(int C) {
+    int cap = 1024 / ((C + 63) / 64);
     if (cap < 16) cap = 16;
     if (cap > TRAIN_MAX_SLOTS) cap = TRAIN_MAX_SLOTS;
+    return cap;
+}
+
+static dim3 ch_grid(long long M, int C) {
+    long long bx = (M + 63) / 64;  // >= 4 passes of 16 pixel rows per workgroup
+    const long long cap = max_slots(C);
     if (bx > cap) bx = cap;
     if (bx < 1) bx = 1;
     return dim3((unsigned)bx, (unsigned)((C + 63) / 64));
 }
 
-size_t train_workspace_bytes(int C) { return ((size_t)TRAIN_MAX_SLOTS * 3 + 3) * C * sizeof(double); }
+static bool vec4_ptrs(std::initializer_list<const void*> ps) {
+    for (const void* q : ps)
+        if (q && ((uintptr_t)q & 15)) return false;
+    return true;
+}
+// four channels per lane with loop-invariant channels: C / 4 divides the 256-thread workgroup
+static bool lane_keeps_channels(int C) { return C % 4 == 0 && C >= 4 && 256 % (C / 4) == 0; }
+
+size_t train_workspace_bytes(int C) { return ((size_t)max_slots(C) * 3 + 3) * C * sizeof(double); }
 
 int bn_train_stats(const float* z, long long M, int C, float eps, float momentum, float* mean, float* rstd,
                    float* rmean, float* rvar, void* ws, hipStream_t s) {
     const dim3 grid = ch_grid(M, C);      // every slot of the grid is written: nothing to clear
-    hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(CH_BLOCK), 0, s, z, M, C, (double*)ws);
+    if (C % 4 == 0 && vec4_ptrs({z}))
+        hipLaunchKernelGGL(bn_stats_v4_kernel, grid, dim3(CH_BLOCK), 0, s, z, M, C, (double*)ws);
+    else
+        hipLaunchKernelGGL(bn_stats_kernel, grid, dim3(CH_BLOCK), 0, s, z, M, C, (double*)ws);
     int rc = hip_check(hipGetLastError(), "bn_stats_kernel");
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 31) / 32), dim3(256), 0, s, (const double*)ws, (int)grid.x, M, C,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, (const double*)ws, (int)grid.x, M, C,
                        eps, momentum, mean, rstd, rmean, rvar);
     return hip_check(hipGetLastError(), "bn_finalize_kernel");
 }
@@ -388,7 +558,10 @@ int epilogue_fwd(const srmi_epi_desc& d, const float* z, const float* mean, cons
     p.z = z; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.alpha = alpha; p.residual = residual;
     p.y = y;
     if (p.M == 0) return SRMI_OK;
-    hipLaunchKernelGGL(epilogue_fwd_kernel, dim3(ew_blocks((size_t)p.M * p.C)), dim3(CH_BLOCK), 0, s, p);
+    if (p.r == 1 && lane_keeps_channels(p.C) && vec4_ptrs({z, y, residual, mean, rstd, gamma, beta, p.alpha_pc ? alpha : nullptr}))
+        hipLaunchKernelGGL(epilogue_fwd_v4_kernel, dim3(ew_blocks((size_t)p.M * p.C / 4)), dim3(CH_BLOCK), 0, s, p);
+    else
+        hipLaunchKernelGGL(epilogue_fwd_kernel, dim3(ew_blocks((size_t)p.M * p.C)), dim3(CH_BLOCK), 0, s, p);
     return hip_check(hipGetLastError(), "epilogue_fwd_kernel");
 }
 
@@ -403,17 +576,23 @@ int epilogue_bwd(const srmi_epi_desc& d, const float* z, const float* dy, const 
     p.nslots = p.M > 0 ? (int)grid.x : 0;
     int rc;
     if (p.M > 0) {
-        hipLaunchKernelGGL(epilogue_bwd_kernel, grid, dim3(CH_BLOCK), 0, s, p);
+        if (p.r == 1 && p.C % 4 == 0 && vec4_ptrs({z, dy, dz, mean, rstd, gamma, beta}))
+            hipLaunchKernelGGL(epilogue_bwd_v4_kernel, grid, dim3(CH_BLOCK), 0, s, p);
+        else
+            hipLaunchKernelGGL(epilogue_bwd_kernel, grid, dim3(CH_BLOCK), 0, s, p);
         rc = hip_check(hipGetLastError(), "epilogue_bwd_kernel");
         if (rc) return rc;
     }
     // totals + parameter gradients (zero slots: all sums are zero)
-    hipLaunchKernelGGL(epilogue_bwd_finalize_kernel, dim3((d.C + 31) / 32 + 1), dim3(256), 0, s, (double*)ws, p.nslots,
+    hipLaunchKernelGGL(epilogue_bwd_finalize_kernel, dim3((d.C + FIN_CH - 1) / FIN_CH + 1), dim3(256), 0, s, (double*)ws, p.nslots,
                        d.C, n_alpha, d.bn, p.Cf, d.shuffle * d.shuffle, p.dcr, dsum1, dsum2, dalpha);
     rc = hip_check(hipGetLastError(), "epilogue_bwd_finalize_kernel");
     if (rc) return rc;
     if (p.M > 0 && d.bn) {
-        hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks((size_t)p.M * p.C)), dim3(CH_BLOCK), 0, s, p);
+        if (lane_keeps_channels(p.C) && vec4_ptrs({z, dz, mean, rstd, gamma}))
+            hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(ew_blocks((size_t)p.M * p.C / 4)), dim3(CH_BLOCK), 0, s, p);
+        else
+            hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks((size_t)p.M * p.C)), dim3(CH_BLOCK), 0, s, p);
         return hip_check(hipGetLastError(), "bn_bwd_apply_kernel");
     }
     return SRMI_OK;

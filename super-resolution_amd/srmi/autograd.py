@@ -90,7 +90,7 @@ class _Workspace:
     def get(self, nbytes, device):
         if nbytes == 0:
             return None
-        key = (device, torch.cuda.current_stream(device).cuda_stream)
+        key = (device, Fn.stream_ptr(device))
         t = self.bufs.get(key)
         if t is None or t.numel() < nbytes:
             t = self.bufs[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)

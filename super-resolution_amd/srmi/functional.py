@@ -26,8 +26,17 @@ def torch_dtype(code: int) -> torch.dtype:
     return _TORCH_DTYPE[code]
 
 
-def stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_GET_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
+def stream_ptr(device=None) -> int:
+    """hipStream_t of torch's current stream on `device` (default: the current device).  The raw accessor costs
+    ~0.3 us; torch.cuda.current_stream() builds a Stream object (~7 us, several per fused op of the training step)."""
+    if _RAW_STREAM is not None and _GET_DEVICE is not None:
+        idx = device.index if device is not None and device.index is not None else _GET_DEVICE()
+        return _RAW_STREAM(idx)
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 def require_cuda(t: torch.Tensor, what="input"):

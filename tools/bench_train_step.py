@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--lr-size", type=int, default=24)
+    ap.add_argument("--host-profile", action="store_true", help="cProfile of the timed steps' enqueue path (main thread) to stderr")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -102,10 +103,20 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
+    prof = None
+    if args.host_profile:
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         d_loss, g_loss = step()
     t_host = time.perf_counter() - t0          # host time to ENQUEUE the steps (no synchronisation inside a step)
+    if prof is not None:
+        import pstats
+        prof.disable()
+        for key in ("tottime", "cumtime"):
+            pstats.Stats(prof, stream=sys.stderr).sort_stats(key).print_stats(30)
     barrier()
     el = time.perf_counter() - t0
     from srmi.tiling import max_over_ranks
