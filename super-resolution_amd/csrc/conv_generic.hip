@@ -231,6 +231,17 @@ __global__ void generic_splitk_reduce_kernel(const float* __restrict__ partial, 
     }
 }
 
+// the same for n % 4 == 0 and 16-byte aligned buffers: 16 bytes per lane and slice (same order of additions per element)
+__global__ void generic_splitk_reduce_v4_kernel(const f32x4* __restrict__ partial, f32x4* __restrict__ y, size_t n4,
+                                                int ksplit) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 v = partial[i];
+#pragma unroll 4
+        for (int z = 1; z < ksplit; ++z) v += partial[(size_t)z * n4 + i];
+        y[i] = v;
+    }
+}
+
 // number of K slices generic_run will use for these parameters (1 = no split)
 static int generic_ksplit(const GenericParams& p) {
     const unsigned gy = p.Cout > 32 ? (unsigned)((p.Cout + 63) / 64) : 1u;
@@ -327,6 +338,13 @@ static int generic_run(const GenericParams& p0) {
         rc = hip_check(hipGetLastError(), "conv_generic_kernel");
     }
     if (rc || p.ksplit <= 1 || !p.partial) return rc;
+    if (out_elems % 4 == 0 && ((uintptr_t)p.partial | (uintptr_t)p.y) % 16 == 0) {
+        size_t blocks = (out_elems / 4 + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(generic_splitk_reduce_v4_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (const f32x4*)p.partial,
+                           (f32x4*)p.y, out_elems / 4, p.ksplit);
+        return hip_check(hipGetLastError(), "generic_splitk_reduce_kernel");
+    }
     size_t blocks = (out_elems + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(generic_splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p.partial, (float*)p.y,

@@ -39,6 +39,8 @@ SHAPES = [
     ("VGG 512->512 @12", 16, 12, 12, 512, 512, 3, 1),
     ("D 512->512 s2 @12", 16, 12, 12, 512, 512, 3, 2),
     ("VGG 512->512 @6", 16, 6, 6, 512, 512, 3, 1),
+    ("D linear 18432->1024", 16, 6, 6, 512, 1024, 6, 1, 0),      # nn.Linear on the flattened 512x6x6 map: a 6x6 conv, pad 0
+    ("D linear 1024->1", 16, 1, 1, 1024, 1, 1, 1, 0),
 ]
 
 
@@ -66,10 +68,10 @@ def main():
 
     print(f"{'layer':26s} {'GFLOP':>7s} | {'fwd us':>8s} {'TF/s':>6s} | {'dgrad us':>8s} {'TF/s':>6s} | {'wgrad us':>8s} {'TF/s':>6s}")
     tot = [0.0, 0.0, 0.0, 0.0]
-    for label, N, H, W, Cin, Cout, k, s in SHAPES:
+    for label, N, H, W, Cin, Cout, k, s, *rest in SHAPES:
         if args.filter and args.filter not in label:
             continue
-        pad = k // 2
+        pad = rest[0] if rest else k // 2
         desc = Fn.make_desc(N, H, W, Cin, Cout, k, stride=s, pad=pad, compute=L.COMPUTE_F32)
         Ho, Wo = (H + 2 * pad - k) // s + 1, (W + 2 * pad - k) // s + 1
         x = torch.randn(N, H, W, Cin, device=dev)
