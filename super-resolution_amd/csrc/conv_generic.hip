@@ -175,6 +175,59 @@ __global__ void generic_pack_dgrad_sub_kernel(const float* __restrict__ w, float
     }
 }
 
+// ---- the same packs for operands without padding, through LDS (both sides of the transposition coalesced) -----------
+// The gather kernels above read 4 bytes per lane at a stride of Cin*kh*kw floats; at the discriminator's first Linear
+// (75 MB of weights, re-packed after every optimizer step in both forms) that was 0.5 ms per training step.
+//
+// forward operand, Cin*taps % 32 == 0 and Cout % 32 == 0: a 32(co) x 32(j = c*taps + tap) tile of the OIHW matrix is read
+// along j and written along co, row j going to row (tap, c) of the packed operand.
+__global__ __launch_bounds__(256) void generic_pack_tiled_kernel(const float* __restrict__ w, float* __restrict__ out,
+                                                                 int Cin, int Cout, int taps) {
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const size_t J = (size_t)Cin * taps;
+    const size_t j0 = (size_t)blockIdx.x * 32;
+    const int co0 = blockIdx.y * 32;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) tile[ty + 8 * r][tx] = w[(size_t)(co0 + ty + 8 * r) * J + j0 + tx];
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const size_t j = j0 + ty + 8 * r;
+        const int c = (int)(j / taps), tap = (int)(j - (size_t)c * taps);
+        out[((size_t)tap * Cin + c) * Cout + co0 + tx] = tile[tx][ty + 8 * r];
+    }
+}
+
+// dgrad operands, Cin % 32 == 0, Cout % 8 == 0, taps <= 128: workgroup (ci block of 32, co) reads the contiguous
+// [32 ci][taps] run of its output channel and writes one 128-byte row of 32 ci per tap, at
+//   general form   [tap][co][ci]          full-map form   [co][tap][ci]   (dgrad_fullmap below)
+__global__ __launch_bounds__(256) void generic_pack_dgrad_rows_kernel(const float* __restrict__ w, float* __restrict__ out,
+                                                                      int Cin, int Cout, int taps, int fullmap) {
+    __shared__ float run[32 * 128 + 32];
+    const int ci0 = blockIdx.x * 32, co = blockIdx.y;
+    const float* src = w + ((size_t)co * Cin + ci0) * taps;
+    const int n = 32 * taps;
+    for (int idx = threadIdx.x; idx < n; idx += 256) run[idx + idx / taps] = src[idx];      // (+1 per ci: bank skew)
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < n; idx += 256) {
+        const int tap = idx >> 5, ci = idx & 31;
+        const size_t row = fullmap ? (size_t)co * taps + tap : (size_t)tap * Cout + co;
+        out[row * Cin + ci0 + ci] = run[ci * taps + tap + ci];
+    }
+}
+
+// A conv whose kernel covers the whole input map without padding (nn.Linear on a flattened feature map): one output
+// pixel per image.  Its input gradient is a plain GEMM  dx[n][(tap, ci)] = sum over co of dz[n][co] * w[co][(tap, ci)] -
+// a FORWARD 1x1 conv of dz [N,1,1,Cout] to kh*kw*Cin channels, whose NHWC output is dx itself.  As a gathering
+// transposed conv every dx pixel walked all kh*kw taps to find the one that exists (1 of 36 at the discriminator's
+// Linear: 275 us for 75 MB of weights).
+bool dgrad_fullmap(const srmi_conv_desc& d) {
+    if (dbg_flags() & (1 << 12)) return false;
+    return d.pad == 0 && d.kh == d.H && d.kw == d.W && d.kh * d.kw > 1 && d.kh * d.kw <= 128 && d.Cin % 32 == 0 &&
+           d.Cout % 8 == 0 && d.Cout <= 65535 && (long long)d.kh * d.kw * d.Cin < 0x7fffffffLL;
+}
+
 size_t generic_dgrad_packed_bytes(const srmi_conv_desc& d) {
     if (dgrad_subpixel(d)) return (size_t)4 * round_up(d.Cout, 8) * round_up(4 * d.Cin, 32) * sizeof(float);
     return (size_t)d.kh * d.kw * round_up(d.Cout, 8) * round_up(d.Cin, 32) * sizeof(float);
@@ -192,6 +245,13 @@ int generic_dgrad_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_pac
     }
     const int K_pad = round_up(d.Cout, 8), N_pad = round_up(d.Cin, 32);
     const size_t total = (size_t)d.kh * d.kw * K_pad * N_pad;
+    if (total == 0) return SRMI_OK;
+    const bool fullmap = dgrad_fullmap(d);
+    if (fullmap || (d.Cin % 32 == 0 && d.Cout % 8 == 0 && d.kh * d.kw <= 128 && d.Cout <= 65535 && total >= (1u << 20))) {
+        hipLaunchKernelGGL(generic_pack_dgrad_rows_kernel, dim3((unsigned)(d.Cin / 32), (unsigned)d.Cout), dim3(256), 0, s,
+                           w_oihw, (float*)w_packed, d.Cin, d.Cout, d.kh * d.kw, fullmap ? 1 : 0);
+        return hip_check(hipGetLastError(), "generic_pack_dgrad_rows_kernel");
+    }
     size_t blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     hipLaunchKernelGGL(generic_pack_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w_oihw, (float*)w_packed,
@@ -206,6 +266,13 @@ size_t generic_packed_bytes(const srmi_conv_desc& d) {
 int generic_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s) {
     const int Cin_pad = round_up(d.Cin, 8), Cout_pad = round_up(d.Cout, 32);
     const size_t total = (size_t)d.kh * d.kw * Cin_pad * Cout_pad;
+    if (total == 0) return SRMI_OK;
+    if (d.Cin % 8 == 0 && d.Cout % 32 == 0 && ((size_t)d.Cin * d.kh * d.kw) % 32 == 0 && d.Cout / 32 <= 65535 &&
+        total >= (1u << 20)) {
+        hipLaunchKernelGGL(generic_pack_tiled_kernel, dim3((unsigned)((size_t)d.Cin * d.kh * d.kw / 32), (unsigned)(d.Cout / 32)),
+                           dim3(256), 0, s, w_oihw, (float*)w_packed, d.Cin, d.Cout, d.kh * d.kw);
+        return hip_check(hipGetLastError(), "generic_pack_tiled_kernel");
+    }
     const int block = 256;
     size_t blocks = (total + block - 1) / block;
     if (blocks > 4096) blocks = 4096;
@@ -358,7 +425,7 @@ static void generic_dgrad_fill(GenericParams& p, const srmi_conv_desc& d, const 
 size_t generic_dgrad_workspace_bytes(const srmi_conv_desc& d, const ConvGeom& g) {
     GenericParams p;
     generic_dgrad_fill(p, d, g);
-    const long long M = dgrad_subpixel(d) ? (long long)d.N * g.Ho * g.Wo : (long long)d.N * d.H * d.W;
+    const long long M = (dgrad_subpixel(d) || dgrad_fullmap(d)) ? (long long)d.N * g.Ho * g.Wo : (long long)d.N * d.H * d.W;
     if (M <= 0 || M > 0x7fffffffLL) return 0;
     p.M = (int)M;
     const int ks = pick_ksplit(p);
@@ -376,7 +443,7 @@ int generic_dgrad_launch(const srmi_conv_desc& d, const ConvGeom& g, const float
     p.vec_ok = d.Cout % 8 == 0 && ((uintptr_t)dz % 16) == 0;
     p.partial = (float*)ws;
     p.partial_stride = ws ? ws_bytes / sizeof(float) : 0;
-    const long long M = dgrad_subpixel(d) ? (long long)d.N * g.Ho * g.Wo : (long long)d.N * d.H * d.W;
+    const long long M = (dgrad_subpixel(d) || dgrad_fullmap(d)) ? (long long)d.N * g.Ho * g.Wo : (long long)d.N * d.H * d.W;
     if (M > 0x7fffffffLL) { set_error("dgrad: N*H*W = %lld exceeds int32", M); return SRMI_EINVAL; }
     p.M = (int)M;
     if (p.M == 0) return SRMI_OK;
@@ -392,6 +459,17 @@ static void generic_dgrad_fill(GenericParams& p, const srmi_conv_desc& d, const 
         p.in_cs = d.Cout; p.out_cs = d.Cin; p.out_co = 0; p.res_cs = d.Cin;
         p.act = SRMI_ACT_NONE; p.r = 2; p.dcr = 1;
         p.Cin_pad = round_up(d.Cout, 8); p.Cout_pad = round_up(4 * d.Cin, 32);
+        p.transposed = 0;
+        p.ksplit = 1;
+        return;
+    }
+    if (dgrad_fullmap(d)) {       // a forward 1x1 conv of dz [N,1,1,Cout] to (tap, ci) channels: its NHWC output is dx
+        const int Cq = d.kh * d.kw * d.Cin;
+        p.N = d.N; p.H = 1; p.W = 1; p.Cin = d.Cout; p.Cout = Cq; p.kh = 1; p.kw = 1; p.stride = 1; p.pad = 0;
+        p.Ho = 1; p.Wo = 1; p.Cf = Cq; p.Hf = 1; p.Wf = 1;
+        p.in_cs = d.Cout; p.out_cs = Cq; p.out_co = 0; p.res_cs = Cq;
+        p.act = SRMI_ACT_NONE; p.r = 1;
+        p.Cin_pad = round_up(d.Cout, 8); p.Cout_pad = round_up(Cq, 32);
         p.transposed = 0;
         p.ksplit = 1;
         return;

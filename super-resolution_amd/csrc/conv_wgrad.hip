@@ -292,6 +292,57 @@ __global__ __launch_bounds__(256) void wgrad2_reduce_kernel(WgradParams p, int K
     }
 }
 
+// =====================================================================================================================
+// Full-map convs (the kernel covers the whole input, no padding: nn.Linear on a flattened feature map).  One output pixel
+// per image, so the contraction runs over the batch only:  dW[co][c][tap] = sum over n of dz[n][co] * x[n][tap][c]  - an
+// outer-product stream that is bound by WRITING dW (75 MB at the discriminator's first Linear).  Pass 1 transposes x to
+// the weight's own order, xT[n][c*taps + tap], in the workspace (N * K floats); pass 2 gives a lane one k = (c, tap) and
+// a workgroup 16 output channels: N coalesced reads of xT, 16 * N FMAs in ascending n (deterministic), 16 coalesced
+// stores.  The tiled kernel above spent 191 us on it (K = 16 per MFMA tile column); this is HBM-bound.
+__global__ __launch_bounds__(256) void wgrad_fullmap_transpose_kernel(const float* __restrict__ x, float* __restrict__ xT,
+                                                                      int N, int Cin, int taps, int in_cs) {
+    const size_t K = (size_t)Cin * taps, total = (size_t)N * K;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const size_t n = idx / K;
+        const int k = (int)(idx - n * K);                 // read order: (tap, c), coalesced
+        const int tap = k / Cin, c = k - tap * Cin;
+        xT[n * K + (size_t)c * taps + tap] = x[(n * taps + tap) * in_cs + c];
+    }
+}
+
+constexpr int FM_CO = 16, FM_NMAX = 256;
+__global__ __launch_bounds__(256) void wgrad_fullmap_kernel(const float* __restrict__ xT, const float* __restrict__ dz,
+                                                            float* __restrict__ dw, int N, int K, int Cout) {
+    __shared__ float dzs[FM_NMAX][FM_CO];
+    const int co0 = blockIdx.y * FM_CO;
+    for (int idx = threadIdx.x; idx < N * FM_CO; idx += 256) {
+        const int n = idx / FM_CO, o = idx % FM_CO;
+        dzs[n][o] = co0 + o < Cout ? dz[(size_t)n * Cout + co0 + o] : 0.f;
+    }
+    __syncthreads();
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    float acc[FM_CO];
+#pragma unroll
+    for (int o = 0; o < FM_CO; ++o) acc[o] = 0.f;
+#pragma unroll 4
+    for (int n = 0; n < N; ++n) {
+        const float xv = xT[(size_t)n * K + k];
+#pragma unroll
+        for (int o = 0; o < FM_CO; ++o) acc[o] = fmaf(dzs[n][o], xv, acc[o]);
+    }
+#pragma unroll
+    for (int o = 0; o < FM_CO; ++o)
+        if (co0 + o < Cout) dw[(size_t)(co0 + o) * K + k] = acc[o];
+}
+
+static bool wgrad_fullmap(const srmi_conv_desc& d, const ConvGeom& g) {
+    if (dbg_flags() & (1 << 12)) return false;
+    return d.pad == 0 && d.kh == d.H && d.kw == d.W && g.Ho == 1 && g.Wo == 1 && d.N >= 1 && d.N <= FM_NMAX &&
+           (long long)d.kh * d.kw * d.Cin < 0x7fffffffLL && (d.Cout + FM_CO - 1) / FM_CO <= 65535 &&
+           (long long)d.kh * d.kw * d.Cin >= 4096;        // small ones stay on the MFMA kernel (one launch)
+}
+
 // tiling / split plan of the tiled kernel, shared by the launch and the workspace query
 struct Wgrad2Plan { int KW, WCI, co_tiles, ci_tiles, slices, cps; long long tiles, M; };
 
@@ -345,6 +396,7 @@ static int wgrad_plan(const srmi_conv_desc& d, const ConvGeom& g, bool allow_spl
 }
 
 size_t wgrad_workspace_bytes(const srmi_conv_desc& d, const ConvGeom& g) {
+    if (wgrad_fullmap(d, g)) return (size_t)d.N * d.kh * d.kw * d.Cin * sizeof(float);
     Wgrad2Plan w2;
     if (wgrad2_plan(d, g, true, &w2)) return w2.slices > 1 ? (size_t)w2.slices * w2.tiles * w2.KW * 4096 * sizeof(float) : 0;
     WgradPlan w;
@@ -358,6 +410,18 @@ int wgrad_launch(const srmi_conv_desc& d, const ConvGeom& g, const float* x, con
     p.x = x; p.dz = dz; p.dw = dw; p.partial = nullptr;
     p.N = d.N; p.H = d.H; p.W = d.W; p.Cin = d.Cin; p.Cout = d.Cout; p.kh = d.kh; p.kw = d.kw;
     p.stride = d.stride; p.pad = d.pad; p.Ho = g.Ho; p.Wo = g.Wo; p.in_cs = g.in_cs;
+    if (wgrad_fullmap(d, g) && ws && ws_bytes >= (size_t)d.N * d.kh * d.kw * d.Cin * sizeof(float)) {
+        const int taps = d.kh * d.kw, K = taps * d.Cin;
+        size_t blocks = ((size_t)d.N * K + 255) / 256;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(wgrad_fullmap_transpose_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, (float*)ws, d.N, d.Cin,
+                           taps, g.in_cs);
+        int rcf = hip_check(hipGetLastError(), "wgrad_fullmap_transpose_kernel");
+        if (rcf) return rcf;
+        hipLaunchKernelGGL(wgrad_fullmap_kernel, dim3((unsigned)((K + 255) / 256), (unsigned)((d.Cout + FM_CO - 1) / FM_CO)),
+                           dim3(256), 0, s, (const float*)ws, dz, dw, d.N, K, d.Cout);
+        return hip_check(hipGetLastError(), "wgrad_fullmap_kernel");
+    }
     Wgrad2Plan w2;
     if (wgrad2_plan(d, g, true, &w2)) {
         if (w2.slices > 1) {

@@ -119,20 +119,27 @@ def test_fused_conv_forward_backward(case):
         _close(resd.grad, leaves["res"].grad, what="dres")
 
 
-def test_linear_as_full_map_conv():
-    g = torch.Generator().manual_seed(11)
-    x = torch.randn(3, 8, 3, 3, generator=g)
-    lin = nn.Linear(72, 10)
+# (3,8,3,3,10): gathering dgrad + MFMA wgrad; the others take the full-map forms (dgrad as a forward GEMM with the
+# [co][tap][ci] operand, the outer-product wgrad through the transposed x) and, at 256 outputs, the tiled forward pack
+@pytest.mark.parametrize("shape", [(3, 8, 3, 3, 10), (5, 128, 6, 6, 40), (4, 128, 6, 6, 256), (16, 32, 12, 12, 64),
+                                   (2, 64, 9, 7, 24)])
+def test_linear_as_full_map_conv(shape):
+    N, Cc, H, W, out = shape
+    g = torch.Generator().manual_seed(11 + out)
+    x = torch.randn(N, Cc, H, W, generator=g)
+    torch.manual_seed(5)
+    lin = nn.Linear(Cc * H * W, out)
     xr = x.clone().requires_grad_(True)
-    ref = torch.nn.functional.leaky_relu(lin(xr.view(3, -1)), 0.01)
-    ref.sum().backward()
-    lind = nn.Linear(72, 10).to(DEV)
+    ref = torch.nn.functional.leaky_relu(lin(xr.view(N, -1)), 0.01)
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    lind = nn.Linear(Cc * H * W, out).to(DEV)
     lind.load_state_dict(lin.state_dict())
     xd = x.to(DEV).requires_grad_(True)
     y = AG.linear(xd, lind, nn.LeakyReLU())
-    assert y.shape == (3, 10, 1, 1)
-    _close(y.reshape(3, 10), ref, 1e-5, "linear")
-    y.sum().backward()
+    assert y.shape == (N, out, 1, 1)
+    _close(y.reshape(N, out), ref, 1e-5, "linear")
+    y.backward(gy.to(DEV).view(N, out, 1, 1))
     _close(lind.weight.grad, lin.weight.grad, what="dW")
     _close(lind.bias.grad, lin.bias.grad, what="db")
     _close(xd.grad, xr.grad, what="dx")
