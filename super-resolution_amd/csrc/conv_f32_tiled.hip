@@ -284,7 +284,6 @@ bool f32t_supported(const GenericParams& p) {
 static const int kBM[5] = {128, 128, 256, 64, 128}, kBN[5] = {128, 64, 32, 64, 32};
 
 static int f32t_bk(const GenericParams& p) {
-    if (dbg_flags() & (1 << 10)) return p.Cin_pad <= 8 ? 8 : 16;   // experiment: half-size chunks, twice the workgroups per CU
     return p.Cin_pad <= 8 ? 8 : (p.Cin_pad >= 32 ? 32 : 16);
 }
 
@@ -338,7 +337,7 @@ static void f32t_magic(int d, unsigned* mul, int* sh) {
 
 // the lean chunk loop's preconditions (see the kernel)
 static bool f32t_fast(const GenericParams& p, int BK) {
-    return p.vec_ok && p.Cin % BK == 0 && p.Cin_pad == p.Cin && !(p.transposed && p.stride > 1) && p.dbg == 0 &&
+    return p.vec_ok && p.Cin % BK == 0 && p.Cin_pad == p.Cin && !(p.transposed && p.stride > 1) && (p.dbg & (31 << 26)) == 0 &&
            p.in_cs % 4 == 0;
 }
 
