@@ -328,7 +328,7 @@ int f32t_ksplit(const GenericParams& p) {
 
 // multiply-shift constants of n / d for 0 <= n < 2^31, d >= 1: s = ceil(log2 d), mul = floor(2^(31+s) / d) + 1 (< 2^32),
 // n / d = (n * mul) >> (31 + s)  (error term n * e / (d * 2^(31+s)) < 1 / d for e <= d <= 2^s)
-static void f32t_magic(int d, unsigned* mul, int* sh) {
+void f32t_magic(int d, unsigned* mul, int* sh) {
     int s = 0;
     while ((1LL << s) < d) ++s;
     *mul = (unsigned)(((1ULL << (31 + s)) / (unsigned long long)d) + 1ULL);

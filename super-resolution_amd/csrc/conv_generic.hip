@@ -106,6 +106,13 @@ __global__ __launch_bounds__(256) void conv_generic_kernel(GenericParams p) {
     generic_epilogue<NT>(p, acc, m0, co0, n, oy, ox, lane, blockIdx.z);
 }
 
+// split-bf16 f32 kernel (conv_b3_f32.hip): chosen from the descriptor, with its own operand format
+bool b3_fwd_ok(const srmi_conv_desc& d);
+bool b3_dgrad_ok(const srmi_conv_desc& d);
+size_t b3_packed_bytes(const srmi_conv_desc& d);
+int b3_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, int transposed, hipStream_t s);
+int b3_launch(const GenericParams& p);
+
 // OIHW f32 -> [tap][Cin_pad][Cout_pad] f32, zero padded
 __global__ void generic_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin, int Cout,
                                     int kh, int kw, int Cin_pad, int Cout_pad, size_t total) {
@@ -228,12 +235,17 @@ bool dgrad_fullmap(const srmi_conv_desc& d) {
            d.Cout % 8 == 0 && d.Cout <= 65535 && (long long)d.kh * d.kw * d.Cin < 0x7fffffffLL;
 }
 
+// the gathering (transposed) dgrad form on the split-bf16 kernel; the sub-pixel and full-map forms keep their own operands
+static bool dgrad_b3(const srmi_conv_desc& d) { return !dgrad_subpixel(d) && !dgrad_fullmap(d) && b3_dgrad_ok(d); }
+
 size_t generic_dgrad_packed_bytes(const srmi_conv_desc& d) {
+    if (dgrad_b3(d)) return b3_packed_bytes(d);
     if (dgrad_subpixel(d)) return (size_t)4 * round_up(d.Cout, 8) * round_up(4 * d.Cin, 32) * sizeof(float);
     return (size_t)d.kh * d.kw * round_up(d.Cout, 8) * round_up(d.Cin, 32) * sizeof(float);
 }
 
 int generic_dgrad_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s) {
+    if (dgrad_b3(d)) return b3_pack(d, w_oihw, w_packed, 1, s);
     if (dgrad_subpixel(d)) {
         const int K_pad = round_up(d.Cout, 8), N_pad = round_up(4 * d.Cin, 32);
         const size_t total = (size_t)4 * K_pad * N_pad;
@@ -260,10 +272,12 @@ int generic_dgrad_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_pac
 }
 
 size_t generic_packed_bytes(const srmi_conv_desc& d) {
+    if (b3_fwd_ok(d)) return b3_packed_bytes(d);
     return (size_t)d.kh * d.kw * round_up(d.Cin, 8) * round_up(d.Cout, 32) * sizeof(float);
 }
 
 int generic_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s) {
+    if (b3_fwd_ok(d)) return b3_pack(d, w_oihw, w_packed, 0, s);
     const int Cin_pad = round_up(d.Cin, 8), Cout_pad = round_up(d.Cout, 32);
     const size_t total = (size_t)d.kh * d.kw * Cin_pad * Cout_pad;
     if (total == 0) return SRMI_OK;
@@ -282,6 +296,7 @@ int generic_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, h
 }
 
 static int generic_run(const struct GenericParams& p);
+
 
 // LDS-tiled kernel for NHWC f32 inputs (conv_f32_tiled.hip); this file's kernel serves the other input layouts / dtypes
 bool f32t_supported(const GenericParams& p);
@@ -324,7 +339,7 @@ static int generic_ksplit(const GenericParams& p) {
 
 static void generic_fill(GenericParams& p, const srmi_conv_args& a, const ConvGeom& g);
 
-static int pick_ksplit(const GenericParams& p) { return f32t_supported(p) ? f32t_ksplit(p) : generic_ksplit(p); }
+static int pick_ksplit(const GenericParams& p) { return (p.b3 || f32t_supported(p)) ? f32t_ksplit(p) : generic_ksplit(p); }
 
 // bytes of workspace that make the forward conv's split-K deterministic (0: it does not split)
 size_t generic_workspace_bytes(const srmi_conv_desc& d, const ConvGeom& g) {
@@ -373,6 +388,7 @@ static void generic_fill(GenericParams& p, const srmi_conv_args& a, const ConvGe
     p.Cin_pad = round_up(d.Cin, 8); p.Cout_pad = round_up(d.Cout, 32);
     p.transposed = 0;
     p.ksplit = 1;
+    p.b3 = b3_fwd_ok(d);
 }
 
 static int generic_run(const GenericParams& p0) {
@@ -394,7 +410,9 @@ static int generic_run(const GenericParams& p0) {
     }
     dim3 grid(gx, gy, (unsigned)p.ksplit);
     int rc;
-    if (tiled) {
+    if (p.b3) {
+        rc = b3_launch(p);
+    } else if (tiled) {
         rc = f32t_launch(p);
     } else {
         if (p.Cout > 32) {
@@ -482,6 +500,7 @@ static void generic_dgrad_fill(GenericParams& p, const srmi_conv_desc& d, const 
     p.Cin_pad = round_up(d.Cout, 8); p.Cout_pad = round_up(d.Cin, 32);
     p.transposed = 1;
     p.ksplit = 1;
+    p.b3 = dgrad_b3(d);
 }
 
 }  // namespace srmi
