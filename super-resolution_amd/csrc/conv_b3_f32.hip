@@ -27,8 +27,9 @@ namespace srmi {
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
 
-constexpr int B3_BK = 32;          // contracted channels per chunk
-constexpr int B3_PITCH = 40;       // bf16 per LDS row (80 bytes)
+// contracted channels per chunk: BK = 32, or 64 for small layers that run one workgroup per CU without a K split (half the
+// chunk hand-offs, each of which costs a global-load latency there).  LDS rows are BK + 8 bf16 (80 / 144 bytes: the 16-byte
+// operand reads of 16 consecutive rows fall into 16 distinct bank groups either way).
 
 __device__ __forceinline__ int b3_fastdiv(int n, unsigned mul, int sh) {
     return (int)(((unsigned long long)(unsigned)n * mul) >> sh);
@@ -58,12 +59,15 @@ __device__ __forceinline__ void b3_split2(float x0, float x1, unsigned& hi, unsi
     lo = __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{q0, q1}, bf16x2_t));
 }
 
-template <int WM, int WN, int TM, int TN>
+template <int WM, int WN, int TM, int TN, int B3_BK>
 __global__ __launch_bounds__(256) void conv_b3_kernel(GenericParams p) {
     static_assert(WM * WN == 4, "four waves per workgroup");
     constexpr int BM = WM * TM * 32, BN = WN * TN * 32;
-    constexpr int A_LOADS = BM * 8 / 256;                 // f32x4 pieces per thread (8 per pixel and chunk)
-    constexpr int B_TOTAL = 3 * BN * 4;                   // 16-byte pieces of the weight tile (4 per row and plane)
+    constexpr int B3_PITCH = B3_BK + 8;
+    constexpr int NPIECE = B3_BK / 4;                     // f32x4 pieces per pixel and chunk
+    constexpr int A_LOADS = BM * NPIECE / 256;            // ... per thread
+    constexpr int BPR = B3_BK / 8;                        // 16-byte pieces per weight row and plane
+    constexpr int B_TOTAL = 3 * BN * BPR;                 // ... of the weight tile
     constexpr int B_LOADS = (B_TOTAL + 255) / 256;
     __shared__ __attribute__((aligned(16))) unsigned short As[3][BM][B3_PITCH];
     __shared__ __attribute__((aligned(16))) unsigned short Bs[3][BN][B3_PITCH];
@@ -90,7 +94,7 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(GenericParams p) {
 #pragma unroll
     for (int l = 0; l < A_LOADS; ++l) {
         const int idx = tid + 256 * l;
-        const int m = m0 + idx / 8;
+        const int m = m0 + idx / NPIECE;
         a_img[l] = 0; a_base[l] = 0; a_rm[l] = 0u; a_cm[l] = 0u;
         if (m < p.M) {
             const int tq = b3_fastdiv(m, p.wo_mul, p.wo_sh);
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(GenericParams p) {
             f32x4 q = {0.f, 0.f, 0.f, 0.f};
             if (v) {
                 const int pix = p.transposed ? a_base[l] - tapoff : a_base[l] + tapoff;
-                q = *(const f32x4*)(xf + (size_t)(a_img[l] + pix) * in_cs + c0 + 4 * (idx & 7));
+                q = *(const f32x4*)(xf + (size_t)(a_img[l] + pix) * in_cs + c0 + 4 * (idx % NPIECE));
             }
             ra[l] = q;
         }
@@ -142,8 +146,8 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(GenericParams p) {
 #pragma unroll
         for (int l = 0; l < B_LOADS; ++l) {
             const int idx = tid + 256 * l;
-            const int plane = idx / (BN * 4), rem = idx % (BN * 4);
-            const int row = rem >> 2, q4 = rem & 3;
+            const int plane = idx / (BN * BPR), rem = idx % (BN * BPR);
+            const int row = rem / BPR, q4 = rem % BPR;
             u32x4 q = {0u, 0u, 0u, 0u};
             if ((B_TOTAL % 256 == 0 || idx < B_TOTAL) && co0 + row < p.Cout) q = *(const u32x4*)(wt + plane * w_plane + (size_t)(co0 + row) * Cin + 8 * q4);
             rb[l] = q;
@@ -158,7 +162,7 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(GenericParams p) {
 #pragma unroll
         for (int l = 0; l < A_LOADS; ++l) {
             const int idx = tid + 256 * l;
-            const int row = idx >> 3, k = 4 * (idx & 7);
+            const int row = idx / NPIECE, k = 4 * (idx % NPIECE);
             unsigned hi[2], mid[2], lo[2];
             b3_split2(ra[l][0], ra[l][1], hi[0], mid[0], lo[0]);
             b3_split2(ra[l][2], ra[l][3], hi[1], mid[1], lo[1]);
@@ -169,8 +173,8 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(GenericParams p) {
 #pragma unroll
         for (int l = 0; l < B_LOADS; ++l) {
             const int idx = tid + 256 * l;
-            const int plane = idx / (BN * 4), rem = idx % (BN * 4);
-            if (B_TOTAL % 256 == 0 || idx < B_TOTAL) *(u32x4*)&Bs[plane][rem >> 2][8 * (rem & 3)] = rb[l];
+            const int plane = idx / (BN * BPR), rem = idx % (BN * BPR);
+            if (B_TOTAL % 256 == 0 || idx < B_TOTAL) *(u32x4*)&Bs[plane][rem / BPR][8 * (rem % BPR)] = rb[l];
         }
     };
 
@@ -261,10 +265,10 @@ static bool b3_enabled() {
 // Decided from the WEIGHT's shape alone (the host caches packed operands per weight, not per input size).
 bool b3_fwd_ok(const srmi_conv_desc& d) {
     return b3_enabled() && d.compute == SRMI_COMPUTE_F32 && d.in_layout == SRMI_NHWC && d.in_dtype == SRMI_F32 &&
-           d.Cin % 32 == 0 && d.Cout % 32 == 0 && d.kh <= 32 && d.kw <= 32 && (long long)d.kh * d.kw * d.Cin >= 256;
+           d.Cin % 32 == 0 && d.Cout % 32 == 0 && d.kh * d.kw <= 25 && (long long)d.kh * d.kw * d.Cin >= 256;
 }
 bool b3_dgrad_ok(const srmi_conv_desc& d) {
-    return b3_enabled() && d.stride == 1 && d.Cin % 32 == 0 && d.Cout % 32 == 0 && d.kh <= 32 && d.kw <= 32 &&
+    return b3_enabled() && d.stride == 1 && d.Cin % 32 == 0 && d.Cout % 32 == 0 && d.kh * d.kw <= 25 &&
            (long long)d.kh * d.kw * d.Cout >= 256;
 }
 
@@ -283,6 +287,29 @@ int b3_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, int tr
 void f32t_magic(int d, unsigned* mul, int* sh);
 void f32t_plan(const GenericParams& p, bool allow_split, int* cfg, int* ks);
 
+// Tile, K split and chunk size.  conv_f32_tiled.hip's plan, except that a small layer it would split over K (partial tiles
+// through the workspace + a reduce launch: ~10 us of fixed cost against ~2 us of MFMA work here) runs UNSPLIT on 64 x 64
+// tiles with 64-channel chunks when that still gives half the CUs a workgroup and at most 24 chunks each.
+static const int kB3BM[5] = {128, 128, 128, 64, 128}, kB3BN[5] = {128, 64, 32, 64, 32};
+
+void b3_plan(const GenericParams& p, bool allow_split, int* cfg, int* ks, int* bk) {
+    *bk = 32;
+    f32t_plan(p, true, cfg, ks);                           // "would split" is a property of the layer, with or without workspace
+    const long long wg3 = (long long)((p.M + 63) / 64) * ((p.Cout + 63) / 64);
+    if (*ks > 1 && p.Cin % 64 == 0 && wg3 >= 128 && (long long)p.kh * p.kw * (p.Cin / 64) <= 24) {
+        *cfg = 3; *ks = 1; *bk = 64;
+        return;
+    }
+    f32t_plan(p, allow_split, cfg, ks);
+    if (*cfg == 2) *cfg = 4;                               // (a 256-pixel tile's three planes do not fit the static LDS)
+}
+
+int b3_ksplit(const GenericParams& p) {
+    int cfg, ks, bk;
+    b3_plan(p, true, &cfg, &ks, &bk);
+    return ks;
+}
+
 // p.b3 is set: the operand is in this file's format.  The launch-time requirements (16-byte activation rows) hold for
 // every dense NHWC tensor; anything else is refused loudly - there is no other kernel that could read this operand.
 int b3_launch(const GenericParams& p0) {
@@ -291,20 +318,22 @@ int b3_launch(const GenericParams& p0) {
         set_error("conv (split-bf16 f32 kernel): input must be NHWC f32 with 16-byte aligned rows");
         return SRMI_EUNSUPPORTED;
     }
-    int c, ks;
-    f32t_plan(p, p.ksplit > 1, &c, &ks);
+    int c, ks, bk;
+    b3_plan(p, p.ksplit > 1, &c, &ks, &bk);               // p.ksplit was fixed by generic_run (1 when there is no workspace)
     f32t_magic(p.Wo > 0 ? p.Wo : 1, &p.wo_mul, &p.wo_sh);
     f32t_magic(p.Ho > 0 ? p.Ho : 1, &p.ho_mul, &p.ho_sh);
-    if (c == 2) c = 4;                                     // (a 256-pixel tile's three planes do not fit the static LDS)
-    static const int kBM[5] = {128, 128, 256, 64, 128}, kBN[5] = {128, 64, 32, 64, 32};
-    const int BM = kBM[c], BN = kBN[c];
+    const int BM = kB3BM[c], BN = kB3BN[c];
     dim3 grid((unsigned)((p.M + BM - 1) / BM), (unsigned)((p.Cout + BN - 1) / BN), (unsigned)p.ksplit);
     hipStream_t s = p.stream;
-    switch (c) {
-        case 0: hipLaunchKernelGGL((conv_b3_kernel<2, 2, 2, 2>), grid, dim3(256), 0, s, p); break;
-        case 1: hipLaunchKernelGGL((conv_b3_kernel<2, 2, 2, 1>), grid, dim3(256), 0, s, p); break;
-        case 3: hipLaunchKernelGGL((conv_b3_kernel<2, 2, 1, 1>), grid, dim3(256), 0, s, p); break;
-        default: hipLaunchKernelGGL((conv_b3_kernel<4, 1, 1, 1>), grid, dim3(256), 0, s, p); break;
+    if (bk == 64) {
+        hipLaunchKernelGGL((conv_b3_kernel<2, 2, 1, 1, 64>), grid, dim3(256), 0, s, p);
+    } else {
+        switch (c) {
+            case 0: hipLaunchKernelGGL((conv_b3_kernel<2, 2, 2, 2, 32>), grid, dim3(256), 0, s, p); break;
+            case 1: hipLaunchKernelGGL((conv_b3_kernel<2, 2, 2, 1, 32>), grid, dim3(256), 0, s, p); break;
+            case 3: hipLaunchKernelGGL((conv_b3_kernel<2, 2, 1, 1, 32>), grid, dim3(256), 0, s, p); break;
+            default: hipLaunchKernelGGL((conv_b3_kernel<4, 1, 1, 1, 32>), grid, dim3(256), 0, s, p); break;
+        }
     }
     return hip_check(hipGetLastError(), "conv_b3_kernel");
 }

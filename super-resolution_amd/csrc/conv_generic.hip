@@ -112,6 +112,7 @@ bool b3_dgrad_ok(const srmi_conv_desc& d);
 size_t b3_packed_bytes(const srmi_conv_desc& d);
 int b3_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, int transposed, hipStream_t s);
 int b3_launch(const GenericParams& p);
+int b3_ksplit(const GenericParams& p);
 
 // OIHW f32 -> [tap][Cin_pad][Cout_pad] f32, zero padded
 __global__ void generic_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin, int Cout,
@@ -339,7 +340,10 @@ static int generic_ksplit(const GenericParams& p) {
 
 static void generic_fill(GenericParams& p, const srmi_conv_args& a, const ConvGeom& g);
 
-static int pick_ksplit(const GenericParams& p) { return (p.b3 || f32t_supported(p)) ? f32t_ksplit(p) : generic_ksplit(p); }
+static int pick_ksplit(const GenericParams& p) {
+    if (p.b3) return b3_ksplit(p);
+    return f32t_supported(p) ? f32t_ksplit(p) : generic_ksplit(p);
+}
 
 // bytes of workspace that make the forward conv's split-K deterministic (0: it does not split)
 size_t generic_workspace_bytes(const srmi_conv_desc& d, const ConvGeom& g) {
