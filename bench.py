@@ -195,8 +195,10 @@ def hbm_bound_layers(plan, units, kms, gen, x):
 
 
 def fp32_path(dev, steps=3):
-    """The exact-f32 path (SRMI_COMPUTE_F32: the <=1e-4 parity path) on the same workload: MP/s and its fraction of the
-    157 TFLOP/s f32-MFMA peak."""
+    """The f32 path (SRMI_COMPUTE_F32: the <=1e-4 parity path) on the same workload: MP/s and its fraction of the
+    157 TFLOP/s f32-MFMA peak.  Convs with Cin, Cout multiples of 32 run on the bf16 matrix cores with operands split
+    into three bf16 (six products per k: an f32 FMA chain's rounding, csrc/conv_b3_f32.hip), so the fraction is against a
+    peak the path is no longer bound by; SRMI_F32_EXACT=1 in the environment keeps the exact-f32 MFMA kernel."""
     gen, x, _, _ = build_generator(dev, "fp32")
     with torch.no_grad():
         gen(x)
@@ -209,7 +211,9 @@ def fp32_path(dev, steps=3):
     mp = BATCH * (4 * LR_H) * (4 * LR_W) / 1e6
     tf = mp * 1e6 * FLOP_PER_OUT_PIXEL / t / 1e12
     return {"value": round(mp / t, 2), "unit": "MP/s", "ms_per_step": round(t * 1e3, 3), "dtype": "f32",
-            "tflops": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "steps": steps}
+            "tflops": round(tf, 2), "peak": PEAK_F32_MFMA_TFLOPS, "frac": round(tf / PEAK_F32_MFMA_TFLOPS, 4), "steps": steps,
+            "arith": "exact f32 MFMA" if os.environ.get("SRMI_F32_EXACT", "0") not in ("", "0") else
+                     "3 x bf16 split operands, 6 MFMA products per k, f32 accumulate (exact f32 MFMA where Cin or Cout % 32 != 0)"}
 
 
 def cpu_baseline(threads, sd, x, info=None):
