@@ -135,7 +135,12 @@ int srmi_conv2d_kernel_name(const srmi_conv_desc* d, char* buf, size_t buf_len);
 int srmi_srcnn_layer_c1in(const srmi_conv_args* a, void* stream);
 int srmi_srcnn_layer_c1out(const srmi_conv_args* a, void* stream);
 
-/* bytes of the kernel-native packed weight buffer for `d`. */
+/* bytes of the kernel-native packed weight buffer for `d`.  The format (and size) belongs to the kernel the dispatcher
+ * selects for `d`: for SRMI_COMPUTE_F32 with NHWC f32 input, Cin and Cout multiples of 32 and <= 25 taps it is the
+ * split-bf16 operand of csrc/conv_b3_f32.hip (three bf16 planes, 6 B per weight; f32 products rebuilt from six bf16
+ * products per k), otherwise [tap][Cin][Cout] f32.  The choice depends on the weight's shape, layouts and dtypes only,
+ * never on N / H / W, so one packed buffer serves every input size.  Environment SRMI_F32_EXACT=1 (read once, at the
+ * first call) keeps every f32 conv on the exact-f32 MFMA kernel and its format. */
 int srmi_conv2d_packed_weight_bytes(const srmi_conv_desc* d, size_t* bytes);
 
 /* OIHW f32 (the `nn.Conv2d.weight` layout, P/ops.py:11) -> kernel-native packed layout; runs on
