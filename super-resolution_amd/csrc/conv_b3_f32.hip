@@ -73,6 +73,13 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(GenericParams p) {
     __shared__ __attribute__((aligned(16))) unsigned short Bs[3][BN][B3_PITCH];
 
     const int tid = threadIdx.x;
+#ifdef SRMI_B3_STAMPS
+    long long stamp[5];
+    stamp[0] = wall_clock64();
+#define B3_STAMP(k) stamp[k] = wall_clock64()
+#else
+#define B3_STAMP(k)
+#endif
     const int lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
@@ -186,11 +193,13 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(GenericParams p) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.f;
 
+    B3_STAMP(1);
     if (kc0 < kc1) {
         load_chunk();
         store_chunk();
     }
     __syncthreads();
+    B3_STAMP(2);
     for (int c = kc0; c < kc1; ++c) {
         const bool more = c + 1 < kc1;
         if (more) load_chunk();                           // in flight under the MFMAs below
@@ -220,6 +229,7 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(GenericParams p) {
         __syncthreads();
     }
 
+    B3_STAMP(3);
     auto epi = [&](auto A) {
         constexpr int a = decltype(A)::value;
         const int mt = m0 + (wm * TM + a) * 32;
@@ -236,6 +246,15 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(GenericParams p) {
     epi(std::integral_constant<int, 0>{});
     if constexpr (TM > 1) epi(std::integral_constant<int, 1>{});
     static_assert(TM <= 2, "epilogue is written out for TM <= 2");
+#ifdef SRMI_B3_STAMPS      // investigation build: phase time stamps of one workgroup over its own first output row (results wrong)
+    if (blockIdx.x == (gridDim.x >> 1) && blockIdx.y == 0 && blockIdx.z == 0) {
+        __syncthreads();
+        if (tid == 0) {
+            B3_STAMP(4);
+            for (int k = 0; k < 5; ++k) ((long long*)((float*)p.y + (size_t)m0 * p.out_cs))[k] = stamp[k];
+        }
+    }
+#endif
 }
 
 // ---- operand pack: OIHW f32 -> [plane][tap][n][k] bf16 --------------------------------------------------------------

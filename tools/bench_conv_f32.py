@@ -103,6 +103,12 @@ def main():
         if args.only in ("", "wgrad"):
             t[2] = timeit(lambda: L.check(lib.srmi_conv2d_wgrad(C.byref(desc), x.data_ptr(), dz.data_ptr(), dw.data_ptr(),
                                                                 ws.data_ptr(), n3.value, st)))
+        if os.environ.get("SRMI_B3_STAMPS"):      # library built with -DSRMI_B3_STAMPS: phase stamps of the middle workgroup
+            torch.cuda.synchronize()
+            for bm in (64, 128):
+                m0 = ((N * Ho * Wo + bm - 1) // bm // 2) * bm
+                st_ = z.flatten()[m0 * Cout:m0 * Cout + 10].view(torch.int64).tolist()
+                print(f"  stamps (tile {bm}), us since kernel entry (prologue, first chunk, K loop, epilogue):", [(v - st_[0]) / 100 for v in st_[1:]])
         print(f"{label:26s} {gf:7.2f} | " + " | ".join(f"{v:8.1f} {gf / v * 1e3:6.1f}" for v in t), flush=True)
         tot[0] += gf
         for i in range(3):
