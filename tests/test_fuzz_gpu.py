@@ -159,3 +159,37 @@ def _k9_cases(n, seed):
 @pytest.mark.parametrize("case", _k9_cases(10, seed=11))
 def test_k9c3_fuzz(case):
     K.test_k9c3_kernel(case)
+
+
+def _f32_cases(n, seed):
+    """the f32 path: split-bf16 kernel where Cin, Cout are multiples of 32 (csrc/conv_b3_f32.hip), exact-f32 MFMA kernel elsewhere"""
+    g = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        k = int(g.choice([1, 3, 3, 3, 5]))
+        Cin = int(g.choice([32, 64, 96, 128, 160, 256])) if i % 4 else int(g.choice([3, 20, 40]))
+        Cout = int(g.choice([32, 64, 96, 128, 256]))
+        case = dict(N=int(g.integers(1, 4)), H=int(g.integers(1, 45)), W=int(g.integers(1, 70)), Cin=Cin, Cout=Cout, k=k,
+                    stride=int(g.choice([1, 1, 2])))
+        kind = i % 6
+        if kind == 0:
+            case.update(act=L.ACT_PRELU, residual=True)
+        elif kind == 1 and Cout % 4 == 0:
+            case.update(act=L.ACT_PRELU, r=2, dcr=bool(g.integers(0, 2)), alpha_pc=int(g.integers(0, 2)))
+        elif kind == 2:
+            case.update(act=L.ACT_LRELU, act_param=float(g.uniform(0.0, 0.3)), out_cs=Cout + 32, out_co=int(g.integers(0, 5)) * 8)
+        elif kind == 3:
+            case.update(act=L.ACT_TANH, out_layout=L.NCHW)
+        elif kind == 4:
+            case.update(act=L.ACT_ADD_RELU, residual=True, in_cs=Cin + 8 * int(g.integers(0, 5)))
+        else:
+            case.update(act=L.ACT_NONE)
+        out.append(case)
+    out.append(dict(N=2, H=96, W=96, Cin=64, Cout=64, k=3, act=L.ACT_RELU))           # several workgroups per CU, 128 x 64 tiles
+    out.append(dict(N=1, H=40, W=40, Cin=64, Cout=256, k=3, act=L.ACT_PRELU, r=2))    # 128 x 128 tiles
+    return out
+
+
+@pytest.mark.parametrize("case", _f32_cases(28, seed=9))
+def test_f32_path_fuzz(case):
+    assert K._run_case(**case) == "generic_f32"

@@ -46,6 +46,12 @@ CASES = [
     (8, 8, 8, 512, 512, 3, 2, True, "lrelu", 1, False, False, False),   # D body.2.body.1 at patch 64
     (8, 8, 8, 256, 512, 3, 1, True, "lrelu", 1, False, False, False),   # D body.2.body.0 at patch 64
     (4, 4, 4, 512, 1024, 4, 1, False, "lrelu", 1, False, False, False), # wide layer, even kernel
+    # split-bf16 forward + dgrad (Cin, Cout multiples of 32), ragged sizes, 1x1 / 5x5 taps, several tiles and K slices
+    (3, 13, 17, 96, 64, 3, 1, True, "lrelu", 1, False, False, False),
+    (2, 9, 30, 64, 160, 5, 1, False, "relu", 1, False, True, False),
+    (5, 7, 7, 256, 32, 1, 1, False, "prelu", 1, False, False, False),
+    (2, 40, 40, 64, 64, 3, 1, True, "prelu", 1, False, True, False),
+    (1, 33, 29, 32, 128, 3, 1, False, "none", 1, False, False, False),
 ]
 
 
