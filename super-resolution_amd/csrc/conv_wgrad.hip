@@ -21,7 +21,13 @@ struct WgradParams {
     int rows;         // N * Ho
     int rows_per_split;
     int co_tiles, ci_tiles;
+    unsigned wo_mul, ho_mul; int wo_sh, ho_sh;   // tiled kernel: multiply-shift division by Wo / Ho (f32t_magic)
 };
+
+void f32t_magic(int d, unsigned* mul, int* sh);
+__device__ __forceinline__ int wg_fastdiv(int n, unsigned mul, int sh) {      // n / d for 0 <= n < 2^31
+    return (int)(((unsigned long long)(unsigned)n * mul) >> sh);
+}
 
 template <int NT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradParams p) {
@@ -179,10 +185,11 @@ __global__ __launch_bounds__(256) void conv_wgrad2_kernel(WgradParams p, int chu
             }
             ra[l] = q;
         }
-        const int mm = mv ? m : 0;
-        const int ox = mm % p.Wo;
-        const int tq = mm / p.Wo;
-        const int oy = tq % p.Ho, n = tq / p.Ho;
+        const int mm = mv ? m : 0;                       // (run-time divisions cost ~40 instructions each: four per chunk were
+        const int tq = wg_fastdiv(mm, p.wo_mul, p.wo_sh);   //  a fifth of the chunk's MFMA time)
+        const int ox = mm - tq * p.Wo;
+        const int n = wg_fastdiv(tq, p.ho_mul, p.ho_sh);
+        const int oy = tq - n * p.Ho;
         const int iy = oy * p.stride - p.pad + ky;
         const bool rv = mv && iy >= 0 && iy < p.H;
         const float* xrow = p.x + ((size_t)n * p.H + (rv ? iy : 0)) * p.W * p.in_cs;
@@ -410,6 +417,8 @@ int wgrad_launch(const srmi_conv_desc& d, const ConvGeom& g, const float* x, con
     p.x = x; p.dz = dz; p.dw = dw; p.partial = nullptr;
     p.N = d.N; p.H = d.H; p.W = d.W; p.Cin = d.Cin; p.Cout = d.Cout; p.kh = d.kh; p.kw = d.kw;
     p.stride = d.stride; p.pad = d.pad; p.Ho = g.Ho; p.Wo = g.Wo; p.in_cs = g.in_cs;
+    f32t_magic(g.Wo > 0 ? g.Wo : 1, &p.wo_mul, &p.wo_sh);
+    f32t_magic(g.Ho > 0 ? g.Ho : 1, &p.ho_mul, &p.ho_sh);
     if (wgrad_fullmap(d, g) && ws && ws_bytes >= (size_t)d.N * d.kh * d.kw * d.Cin * sizeof(float)) {
         const int taps = d.kh * d.kw, K = taps * d.Cin;
         size_t blocks = ((size_t)d.N * K + 255) / 256;
