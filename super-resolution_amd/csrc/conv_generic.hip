@@ -113,6 +113,12 @@ size_t b3_packed_bytes(const srmi_conv_desc& d);
 int b3_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, int transposed, hipStream_t s);
 int b3_launch(const GenericParams& p);
 int b3_ksplit(const GenericParams& p);
+// its 3x3 / 64-channel halo-tile sibling (conv_b3h_f32.hip; p.b3 == 2)
+bool b3h_fwd_ok(const srmi_conv_desc& d);
+bool b3h_dgrad_ok(const srmi_conv_desc& d);
+size_t b3h_packed_bytes(const srmi_conv_desc& d);
+int b3h_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, int transposed, hipStream_t s);
+int b3h_launch(const GenericParams& p);
 
 // OIHW f32 -> [tap][Cin_pad][Cout_pad] f32, zero padded
 __global__ void generic_pack_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin, int Cout,
@@ -238,14 +244,17 @@ bool dgrad_fullmap(const srmi_conv_desc& d) {
 
 // the gathering (transposed) dgrad form on the split-bf16 kernel; the sub-pixel and full-map forms keep their own operands
 static bool dgrad_b3(const srmi_conv_desc& d) { return !dgrad_subpixel(d) && !dgrad_fullmap(d) && b3_dgrad_ok(d); }
+static bool dgrad_b3h(const srmi_conv_desc& d) { return !dgrad_subpixel(d) && !dgrad_fullmap(d) && b3h_dgrad_ok(d); }
 
 size_t generic_dgrad_packed_bytes(const srmi_conv_desc& d) {
+    if (dgrad_b3h(d)) return b3h_packed_bytes(d);
     if (dgrad_b3(d)) return b3_packed_bytes(d);
     if (dgrad_subpixel(d)) return (size_t)4 * round_up(d.Cout, 8) * round_up(4 * d.Cin, 32) * sizeof(float);
     return (size_t)d.kh * d.kw * round_up(d.Cout, 8) * round_up(d.Cin, 32) * sizeof(float);
 }
 
 int generic_dgrad_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s) {
+    if (dgrad_b3h(d)) return b3h_pack(d, w_oihw, w_packed, 1, s);
     if (dgrad_b3(d)) return b3_pack(d, w_oihw, w_packed, 1, s);
     if (dgrad_subpixel(d)) {
         const int K_pad = round_up(d.Cout, 8), N_pad = round_up(4 * d.Cin, 32);
@@ -273,11 +282,13 @@ int generic_dgrad_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_pac
 }
 
 size_t generic_packed_bytes(const srmi_conv_desc& d) {
+    if (b3h_fwd_ok(d)) return b3h_packed_bytes(d);
     if (b3_fwd_ok(d)) return b3_packed_bytes(d);
     return (size_t)d.kh * d.kw * round_up(d.Cin, 8) * round_up(d.Cout, 32) * sizeof(float);
 }
 
 int generic_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s) {
+    if (b3h_fwd_ok(d)) return b3h_pack(d, w_oihw, w_packed, 0, s);
     if (b3_fwd_ok(d)) return b3_pack(d, w_oihw, w_packed, 0, s);
     const int Cin_pad = round_up(d.Cin, 8), Cout_pad = round_up(d.Cout, 32);
     const size_t total = (size_t)d.kh * d.kw * Cin_pad * Cout_pad;
@@ -341,6 +352,7 @@ static int generic_ksplit(const GenericParams& p) {
 static void generic_fill(GenericParams& p, const srmi_conv_args& a, const ConvGeom& g);
 
 static int pick_ksplit(const GenericParams& p) {
+    if (p.b3 == 2) return 1;
     if (p.b3) return b3_ksplit(p);
     return f32t_supported(p) ? f32t_ksplit(p) : generic_ksplit(p);
 }
@@ -392,7 +404,7 @@ static void generic_fill(GenericParams& p, const srmi_conv_args& a, const ConvGe
     p.Cin_pad = round_up(d.Cin, 8); p.Cout_pad = round_up(d.Cout, 32);
     p.transposed = 0;
     p.ksplit = 1;
-    p.b3 = b3_fwd_ok(d);
+    p.b3 = b3h_fwd_ok(d) ? 2 : b3_fwd_ok(d) ? 1 : 0;
 }
 
 static int generic_run(const GenericParams& p0) {
@@ -414,7 +426,9 @@ static int generic_run(const GenericParams& p0) {
     }
     dim3 grid(gx, gy, (unsigned)p.ksplit);
     int rc;
-    if (p.b3) {
+    if (p.b3 == 2) {
+        rc = b3h_launch(p);
+    } else if (p.b3) {
         rc = b3_launch(p);
     } else if (tiled) {
         rc = f32t_launch(p);
@@ -504,7 +518,7 @@ static void generic_dgrad_fill(GenericParams& p, const srmi_conv_desc& d, const 
     p.Cin_pad = round_up(d.Cout, 8); p.Cout_pad = round_up(d.Cin, 32);
     p.transposed = 1;
     p.ksplit = 1;
-    p.b3 = dgrad_b3(d);
+    p.b3 = dgrad_b3h(d) ? 2 : dgrad_b3(d) ? 1 : 0;
 }
 
 }  // namespace srmi
