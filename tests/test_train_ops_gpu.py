@@ -52,6 +52,10 @@ CASES = [
     (5, 7, 7, 256, 32, 1, 1, False, "prelu", 1, False, False, False),
     (2, 40, 40, 64, 64, 3, 1, True, "prelu", 1, False, True, False),
     (1, 33, 29, 32, 128, 3, 1, False, "none", 1, False, False, False),
+    # halo-tile split kernel (3x3, 64 contracted channels): non-square ragged maps, no BN, wide outputs
+    (2, 32, 48, 64, 64, 3, 1, False, "relu", 1, False, False, False),
+    (3, 13, 21, 64, 128, 3, 1, False, "lrelu", 1, False, True, False),
+    (1, 9, 70, 64, 256, 3, 1, False, "prelu", 2, False, False, False),
 ]
 
 
