@@ -291,6 +291,43 @@ bool b3_dgrad_ok(const srmi_conv_desc& d) {
            (long long)d.kh * d.kw * d.Cout >= 256;
 }
 
+// Operand of the stride-2 dgrad in its sub-pixel form (conv_generic.hip: dgrad_subpixel - a forward 2x2 conv of dz to
+// 4 Cin channels): [plane][tap (a, b)][n = (py, px, ci)][k = co]; taps that do not exist for a parity are zero.
+__global__ __launch_bounds__(256) void b3_pack_sub_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int Cin,
+                                                          int Cout, size_t plane) {
+    const int Nn = 4 * Cin;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < plane; idx += (size_t)gridDim.x * 256) {
+        const int k = (int)(idx % Cout);
+        const size_t t1 = idx / Cout;
+        const int nn = (int)(t1 % Nn);
+        const int tap = (int)(t1 / Nn);
+        const int sub = nn / Cin, ci = nn - sub * Cin;
+        const int py = sub >> 1, px = sub & 1, a = tap >> 1, b = tap & 1;
+        const int ky = py + 1 - 2 * a, kx = px + 1 - 2 * b;
+        float v = 0.f;
+        if (ky >= 0 && ky < 3 && kx >= 0 && kx < 3) v = w[(((size_t)k * Cin + ci) * 3 + ky) * 3 + kx];
+        unsigned hi, mid, lo;
+        b3_split(v, hi, mid, lo);
+        out[idx] = (unsigned short)hi;
+        out[plane + idx] = (unsigned short)mid;
+        out[2 * plane + idx] = (unsigned short)lo;
+    }
+}
+
+bool b3_dgrad_sub_ok(const srmi_conv_desc& d) { return b3_enabled() && d.Cin % 32 == 0 && d.Cout % 32 == 0 && !(dbg_flags() & (1 << 8)); }
+
+size_t b3_sub_packed_bytes(const srmi_conv_desc& d) { return (size_t)3 * 4 * 4 * d.Cin * d.Cout * sizeof(unsigned short); }
+
+int b3_pack_sub(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s) {
+    const size_t plane = (size_t)4 * 4 * d.Cin * d.Cout;
+    if (plane == 0) return SRMI_OK;
+    size_t blocks = (plane + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(b3_pack_sub_kernel, dim3((unsigned)blocks), dim3(256), 0, s, w_oihw, (unsigned short*)w_packed, d.Cin, d.Cout,
+                       plane);
+    return hip_check(hipGetLastError(), "b3_pack_sub_kernel");
+}
+
 size_t b3_packed_bytes(const srmi_conv_desc& d) { return (size_t)3 * d.kh * d.kw * d.Cin * d.Cout * sizeof(unsigned short); }
 
 int b3_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, int transposed, hipStream_t s) {

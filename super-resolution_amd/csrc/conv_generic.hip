@@ -113,6 +113,9 @@ size_t b3_packed_bytes(const srmi_conv_desc& d);
 int b3_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, int transposed, hipStream_t s);
 int b3_launch(const GenericParams& p);
 int b3_ksplit(const GenericParams& p);
+bool b3_dgrad_sub_ok(const srmi_conv_desc& d);
+size_t b3_sub_packed_bytes(const srmi_conv_desc& d);
+int b3_pack_sub(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s);
 // its 3x3 / 64-channel halo-tile sibling (conv_b3h_f32.hip; p.b3 == 2)
 bool b3h_fwd_ok(const srmi_conv_desc& d);
 bool b3h_dgrad_ok(const srmi_conv_desc& d);
@@ -249,6 +252,7 @@ static bool dgrad_b3h(const srmi_conv_desc& d) { return !dgrad_subpixel(d) && !d
 size_t generic_dgrad_packed_bytes(const srmi_conv_desc& d) {
     if (dgrad_b3h(d)) return b3h_packed_bytes(d);
     if (dgrad_b3(d)) return b3_packed_bytes(d);
+    if (dgrad_subpixel(d) && b3_dgrad_sub_ok(d)) return b3_sub_packed_bytes(d);
     if (dgrad_subpixel(d)) return (size_t)4 * round_up(d.Cout, 8) * round_up(4 * d.Cin, 32) * sizeof(float);
     return (size_t)d.kh * d.kw * round_up(d.Cout, 8) * round_up(d.Cin, 32) * sizeof(float);
 }
@@ -256,6 +260,7 @@ size_t generic_dgrad_packed_bytes(const srmi_conv_desc& d) {
 int generic_dgrad_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s) {
     if (dgrad_b3h(d)) return b3h_pack(d, w_oihw, w_packed, 1, s);
     if (dgrad_b3(d)) return b3_pack(d, w_oihw, w_packed, 1, s);
+    if (dgrad_subpixel(d) && b3_dgrad_sub_ok(d)) return b3_pack_sub(d, w_oihw, w_packed, s);
     if (dgrad_subpixel(d)) {
         const int K_pad = round_up(d.Cout, 8), N_pad = round_up(4 * d.Cin, 32);
         const size_t total = (size_t)4 * K_pad * N_pad;
@@ -497,6 +502,7 @@ static void generic_dgrad_fill(GenericParams& p, const srmi_conv_desc& d, const 
         p.Cin_pad = round_up(d.Cout, 8); p.Cout_pad = round_up(4 * d.Cin, 32);
         p.transposed = 0;
         p.ksplit = 1;
+        p.b3 = b3_dgrad_sub_ok(d) ? 1 : 0;               // the split-bf16 kernel with the sub-pixel operand and store
         return;
     }
     if (dgrad_fullmap(d)) {       // a forward 1x1 conv of dz [N,1,1,Cout] to (tap, ci) channels: its NHWC output is dx
