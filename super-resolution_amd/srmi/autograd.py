@@ -103,10 +103,52 @@ _WS = _Workspace()
 _WS_TRAIN = _Workspace()      # f64 partial slots of the per-channel reductions (BN statistics, epilogue backward)
 
 
+_TRAIN_WS_BYTES = {}
+
+
 def _train_ws(C_, device):
-    n = C.c_size_t(0)
-    L.check(L.load().srmi_train_workspace_bytes(C_, C.byref(n)))
-    return _WS_TRAIN.get(n.value, device)
+    nb = _TRAIN_WS_BYTES.get(C_)
+    if nb is None:
+        n = C.c_size_t(0)
+        L.check(L.load().srmi_train_workspace_bytes(C_, C.byref(n)))
+        nb = _TRAIN_WS_BYTES[C_] = n.value
+    return _WS_TRAIN.get(nb, device)
+
+
+class _ConvPlan:
+    """Everything about one conv shape that does not depend on the tensors: the descriptor, its output shape and the three
+    workspace sizes.  Cached per shape: the SRGAN step runs ~140 fused ops, each of which used to build its descriptor and
+    ask the library for its workspace sizes on every call (4-5 ctypes round trips per op)."""
+
+    __slots__ = ("desc", "Ho", "Wo", "ws_fwd", "ws_dgrad", "ws_wgrad", "dgrad_pack_bytes")
+
+    def __init__(self, key):
+        N, H, W, Cin, Cout, kh, kw, stride, pad = key
+        lib = L.load()
+        self.desc = Fn.make_desc(N, H, W, Cin, Cout, (kh, kw), stride=stride, pad=pad, compute=L.COMPUTE_F32)
+        _, _, self.Ho, self.Wo = Fn.out_shape(self.desc)
+        n = C.c_size_t(0)
+        L.check(lib.srmi_conv2d_workspace_bytes(C.byref(self.desc), C.byref(n)))
+        self.ws_fwd = n.value
+        L.check(lib.srmi_conv2d_dgrad_workspace_bytes(C.byref(self.desc), C.byref(n)))
+        self.ws_dgrad = n.value
+        L.check(lib.srmi_conv2d_wgrad_workspace_bytes(C.byref(self.desc), C.byref(n)))
+        self.ws_wgrad = n.value
+        L.check(lib.srmi_conv2d_dgrad_packed_weight_bytes(C.byref(self.desc), C.byref(n)))
+        self.dgrad_pack_bytes = n.value
+
+
+_PLANS = {}
+
+
+def _conv_plan(N, H, W, Cin, Cout, kh, kw, stride, pad):
+    key = (N, H, W, Cin, Cout, kh, kw, stride, pad)
+    pl = _PLANS.get(key)
+    if pl is None:
+        if len(_PLANS) > 4096:
+            _PLANS.clear()
+        pl = _PLANS[key] = _ConvPlan(key)
+    return pl
 
 
 class _PackCache:
@@ -158,8 +200,8 @@ class FusedConvFn(torch.autograd.Function):
         dev = x.device
         N, Cin, H, W = x.shape
         Cout, _, kh, kw = weight.shape
-        desc = Fn.make_desc(N, H, W, Cin, Cout, (kh, kw), stride=cfg.stride, pad=cfg.pad, compute=L.COMPUTE_F32)
-        _, _, Ho, Wo = Fn.out_shape(desc)
+        plan = _conv_plan(N, H, W, Cin, Cout, kh, kw, cfg.stride, cfg.pad)
+        desc, Ho, Wo = plan.desc, plan.Ho, plan.Wo
         w = weight.detach().contiguous()
         wp = _PACKS.get("fwd", weight, lambda: Fn.pack_weights(desc, w))
         shift = bias.detach().contiguous() if bias is not None else None
@@ -167,10 +209,8 @@ class FusedConvFn(torch.autograd.Function):
         # scale NULL = 1: lets the kernel split K on small maps; the workspace makes that split deterministic
         a = L.ConvArgs()
         Fn.fill_args(a, desc, x, wp, None, shift, None, None, z)
-        nws = C.c_size_t(0)
-        L.check(lib.srmi_conv2d_workspace_bytes(C.byref(desc), C.byref(nws)))
-        wsk = _WS.get(nws.value, dev)
-        L.check(lib.srmi_conv2d_fwd_ws(C.byref(a), _ptr(wsk), nws.value, st))
+        wsk = _WS.get(plan.ws_fwd, dev)
+        L.check(lib.srmi_conv2d_fwd_ws(C.byref(a), _ptr(wsk), plan.ws_fwd, st))
 
         bn = cfg.bn
         mean = rstd = None
@@ -201,7 +241,7 @@ class FusedConvFn(torch.autograd.Function):
         L.check(lib.srmi_epilogue_fwd(C.byref(ed), z.data_ptr(), _ptr(mean), _ptr(rstd), _ptr(g_), _ptr(b_), _ptr(a),
                                       _ptr(res), y.data_ptr(), st))
         ctx.save_for_backward(x, w, z, mean, rstd, g_, b_, a)
-        ctx.cfg, ctx.desc, ctx.ed = cfg, desc, ed
+        ctx.cfg, ctx.desc, ctx.ed, ctx.plan = cfg, desc, ed, plan
         ctx.has_bias, ctx.has_res = bias is not None, residual is not None
         ctx.weight_obj = weight        # cache key of the packed dgrad operand (an input: no reference cycle)
         return y
@@ -212,7 +252,7 @@ class FusedConvFn(torch.autograd.Function):
         lib = L.load()
         st = Fn.stream_ptr()
         x, w, z, mean, rstd, gamma, beta, alpha = ctx.saved_tensors
-        cfg, desc, ed = ctx.cfg, ctx.desc, ctx.ed
+        cfg, desc, ed, plan = ctx.cfg, ctx.desc, ctx.ed, ctx.plan
         dev = x.device
         dy = nhwc(dy)
         Cout = desc.Cout
@@ -226,26 +266,21 @@ class FusedConvFn(torch.autograd.Function):
                                       _ptr(dalpha), ws.data_ptr(), st))
         need = ctx.needs_input_grad
         dx = dw = dbias = dgamma = dbeta = None
-        nws = C.c_size_t(0)
         if need[1]:
             dw = torch.empty_like(w)
-            L.check(lib.srmi_conv2d_wgrad_workspace_bytes(C.byref(desc), C.byref(nws)))
-            wsk = _WS.get(nws.value, dev)
+            wsk = _WS.get(plan.ws_wgrad, dev)
             L.check(lib.srmi_conv2d_wgrad(C.byref(desc), x.data_ptr(), dz.data_ptr(), dw.data_ptr(), _ptr(wsk),
-                                          nws.value, st))
+                                          plan.ws_wgrad, st))
         if need[0]:
             def pack_dgrad():
-                nbytes = C.c_size_t(0)
-                L.check(lib.srmi_conv2d_dgrad_packed_weight_bytes(C.byref(desc), C.byref(nbytes)))
-                wd_ = torch.empty(nbytes.value, dtype=torch.uint8, device=dev)
+                wd_ = torch.empty(plan.dgrad_pack_bytes, dtype=torch.uint8, device=dev)
                 L.check(lib.srmi_conv2d_dgrad_pack_weights(C.byref(desc), w.data_ptr(), wd_.data_ptr(), st))
                 return wd_
             wd = _PACKS.get("dgrad", ctx.weight_obj, pack_dgrad)
             dx = torch.empty_like(x)
-            L.check(lib.srmi_conv2d_dgrad_workspace_bytes(C.byref(desc), C.byref(nws)))
-            wsk = _WS.get(nws.value, dev)
+            wsk = _WS.get(plan.ws_dgrad, dev)
             L.check(lib.srmi_conv2d_dgrad(C.byref(desc), dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), _ptr(wsk),
-                                          nws.value, st))
+                                          plan.ws_dgrad, st))
         if cfg.bn is not None:
             dgamma, dbeta = dsum2, dsum1
             # the bias of a conv feeding train-mode BN has an exactly-zero gradient (BN removes the mean)
