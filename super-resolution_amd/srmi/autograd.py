@@ -203,7 +203,9 @@ class FusedConvFn(torch.autograd.Function):
         plan = _conv_plan(N, H, W, Cin, Cout, kh, kw, cfg.stride, cfg.pad)
         desc, Ho, Wo = plan.desc, plan.Ho, plan.Wo
         w = weight.detach().contiguous()
-        wp = _PACKS.get("fwd", weight, lambda: Fn.pack_weights(desc, w))
+        # (the operand format belongs to the kernel the library selects, which may depend on H, W, stride and pad - never on
+        # N: sub-pixel / full-map / halo-tile forms - so those are part of the cache key)
+        wp = _PACKS.get(("fwd", H, W, cfg.stride, cfg.pad), weight, lambda: Fn.pack_weights(desc, w))
         shift = bias.detach().contiguous() if bias is not None else None
         z = _empty_cl((N, Cout, Ho, Wo), dev)
         # scale NULL = 1: lets the kernel split K on small maps; the workspace makes that split deterministic
@@ -276,7 +278,7 @@ class FusedConvFn(torch.autograd.Function):
                 wd_ = torch.empty(plan.dgrad_pack_bytes, dtype=torch.uint8, device=dev)
                 L.check(lib.srmi_conv2d_dgrad_pack_weights(C.byref(desc), w.data_ptr(), wd_.data_ptr(), st))
                 return wd_
-            wd = _PACKS.get("dgrad", ctx.weight_obj, pack_dgrad)
+            wd = _PACKS.get(("dgrad", desc.H, desc.W, desc.stride, desc.pad), ctx.weight_obj, pack_dgrad)
             dx = torch.empty_like(x)
             wsk = _WS.get(plan.ws_dgrad, dev)
             L.check(lib.srmi_conv2d_dgrad(C.byref(desc), dz.data_ptr(), wd.data_ptr(), dx.data_ptr(), _ptr(wsk),

@@ -155,6 +155,31 @@ def test_linear_as_full_map_conv(shape):
     _close(xd.grad, xr.grad, what="dx")
 
 
+def test_same_weight_at_different_input_sizes():
+    """The packed operand's format depends on the input size (stride-2 dgrad: sub-pixel form on even maps, gathering form on
+    odd ones; a 6x6 kernel on a 6x6 map is a full-map conv): one module applied to several sizes must re-pack."""
+    torch.manual_seed(3)
+    for (Cin, Cout, k, stride, sizes) in [(64, 64, 3, 2, [(8, 8), (9, 11), (8, 8)]), (32, 40, 6, 1, [(6, 6), (9, 8), (6, 6)]),
+                                          (64, 64, 3, 1, [(8, 8), (5, 13)])]:
+        ref_conv = nn.Conv2d(Cin, Cout, k, stride=stride, padding=k // 2 if k == 3 else 0)
+        conv = nn.Conv2d(Cin, Cout, k, stride=stride, padding=k // 2 if k == 3 else 0).to(DEV)
+        conv.load_state_dict(ref_conv.state_dict())
+        for (H, W) in sizes:
+            x = torch.randn(2, Cin, H, W)
+            xr = x.clone().requires_grad_(True)
+            yr = ref_conv(xr)
+            gy = torch.randn(yr.shape)
+            ref_conv.zero_grad()
+            yr.backward(gy)
+            xd = x.to(DEV).requires_grad_(True)
+            y = AG.fused_conv(xd, conv, None, None)
+            _close(y, yr, 1e-4, f"y {H}x{W}")
+            conv.zero_grad()
+            y.backward(gy.to(DEV))
+            _close(xd.grad, xr.grad, what=f"dx {H}x{W}")
+            _close(conv.weight.grad, ref_conv.weight.grad, what=f"dw {H}x{W}")
+
+
 @pytest.mark.parametrize("shape", [(2, 8, 6, 6), (1, 3, 7, 9), (2, 64, 24, 24)])
 def test_maxpool2x2(shape):
     g = torch.Generator().manual_seed(sum(shape))
