@@ -21,6 +21,9 @@ void set_error(const char* fmt, ...) {
 //   32          disable the XCD-aware block -> tile remap        128  4-wave fused ResBlock
 //   256         4-wave Cin=64 / K-chunked kernels                512  fused ResBlock without the residual read
 //   bits 23-24  thin-Cout kernel: cache policy of its row loads (0 = nt, the default; 1 = none; 2 = nt+sc1...), bit 25: nt stores
+//   f32 path (results stay correct): 256 sub-pixel dgrad on the exact kernel, 512 no halo-tile split kernel, 4096 no full-map
+//               forms, 16384 gathering stride-2 dgrad, bit 24 / 25 the no-LDS forward / old wgrad; bits 26-30 ablate the tiled
+//               exact-f32 kernel (results wrong).  SRMI_F32_EXACT=1 (separate variable): no split-bf16 kernels at all.
 int dbg_flags() {
     static const int v = [] { const char* e = getenv("SRMI_DBG"); return e ? atoi(e) : 0; }();
     return v;
