@@ -15,7 +15,7 @@ void set_error(const char* fmt, ...) {
     va_end(ap);
 }
 
-// SRMI_DBG: profiling-only ablation switches (results are WRONG with bits 1..16 or 512 set; never set in production).
+// SRMI_DBG (ablation build only, -DSRMI_ABLATE): profiling-only ablation switches (results are WRONG with bits 1..16 or 512 set; never set in production).
 //   1/2/4/8/16  fused ResBlock: skip staging / conv 1 / epilogue / conv 2 / T write (phase timing; 1/2/4 also in the
 //               Cin=64 kernel: staging / MFMA loop / epilogue)
 //   32          disable the XCD-aware block -> tile remap        128  4-wave fused ResBlock
@@ -24,8 +24,14 @@ void set_error(const char* fmt, ...) {
 //   f32 path (results stay correct): 256 sub-pixel dgrad on the exact kernel, 512 no halo-tile split kernel, 4096 no full-map
 //               forms, 16384 gathering stride-2 dgrad, bit 24 / 25 the no-LDS forward / old wgrad; bits 26-30 ablate the tiled
 //               exact-f32 kernel (results wrong).  SRMI_F32_EXACT=1 (separate variable): no split-bf16 kernels at all.
+#ifdef SRMI_ABLATE
 int dbg_flags() {
     static const int v = [] { const char* e = getenv("SRMI_DBG"); return e ? atoi(e) : 0; }();
+    return v;
+}
+
+int exp_flags() {
+    static const int v = [] { const char* e = getenv("SRMI_EXP"); return e ? atoi(e) : 0; }();
     return v;
 }
 
@@ -33,6 +39,7 @@ int dbg_thin_rows() {
     static const int v = [] { const char* e = getenv("SRMI_THIN_RB"); return e ? atoi(e) : 0; }();
     return v;
 }
+#endif
 
 int hip_check(hipError_t e, const char* what) {
     if (e == hipSuccess) return SRMI_OK;

@@ -69,10 +69,20 @@ static inline int pick_tile3x3(int N, int H, int W) {
     return bi;
 }
 
-// Investigation knobs (ablation switches of tools/ablate_*.py), read from the environment ONCE per process:
-// SRMI_DBG = bit mask that skips kernel phases, SRMI_THIN_RB = rows per band of the thin kernel.  0 = product path.
+// Investigation knobs (ablation switches of tools/ablate_*): they exist only in the ABLATION build of the library
+// (`make ablate` -> lib/libsrmi_ablate.so, compiled with -DSRMI_ABLATE; the tools point SRMI_LIB at it), where they are
+// read from the environment once per process: SRMI_DBG = bit mask that skips kernel phases (results wrong by
+// construction), SRMI_EXP = scheduling experiments (results stay correct), SRMI_THIN_RB = rows per band of the thin
+// kernel.  The product library ignores all three: the functions are constant 0 there.
+#ifdef SRMI_ABLATE
 int dbg_flags();
+int exp_flags();
 int dbg_thin_rows();
+#else
+static inline int dbg_flags() { return 0; }
+static inline int exp_flags() { return 0; }
+static inline int dbg_thin_rows() { return 0; }
+#endif
 
 // kernel families (dispatch.cpp decides, the .hip files implement)
 enum Kernel { K_GENERIC_F32 = 0, K_C64_BF16 = 1, K_THIN_BF16 = 2, K_K9C3_BF16 = 3, K_CIN_BF16 = 4, K_PW_BF16 = 5, K_C1OUT_BF16 = 6, K_K9C1_BF16 = 7 };

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(NW * 64, WGPC) void conv_c64_kernel(C64Params p) {
     constexpr int NDMA = WAVE_BYTES / 1024;            // LDS-DMA instructions per wave and tap (2 or 1)
     constexpr int ROWP = (TW + 2 + PITCH - 1) / PITCH * PITCH;  // LDS row pitch in pixels: even, so a row starts on a 256-B bank row
     static_assert(ROWP % 2 == 0, "pixel pairs must not straddle rows");
-    auto swz = [](int P, int col) { return ROWP % 16 == 0 ? (P >> 1) & 7 : (col >> 1) & 7; };   // swizzle key: the same for every row
+    auto swz = [](int P, int col) { return ROWP % 8 == 0 ? c64_key(P) : c64_key(col); };   // swizzle key: the same for every row
     constexpr int IN_BYTES = (TH + 2) * ROWP * 128;
     // ONE shared array (input tile | weight ring): a second __shared__ object next to an LDS-DMA
     // target makes hipcc drain vmcnt before every ds_read (cdna guide, "three .s-level traps").
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(NW * 64, WGPC) void conv_c64_kernel(C64Params p) {
         for (int g = 0; g < NA; ++g) {
             const int col = g * CPT + c0, gx = x0 - 1 + col;
             const unsigned coff = (gx >= 0 && gx < p.W) ? (unsigned)gx * p.in_cs * 2 + ch * 16 : OOB_COL;
-            la[g] = col * 128 + ((ch ^ ((col >> 1) & 7)) << 4);     // ROWP % 16 == 0: the swizzle key depends on the column only
+            la[g] = col * 128 + ((ch ^ c64_key(col)) << 4);     // ROWP % 16 == 0: the swizzle key depends on the column only
 #pragma unroll
             for (int row = 0; row < XR; ++row) {
                 const int gy = y0 - 1 + row;                               // wave-uniform
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(NW * 64, WGPC) void conv_c64_kernel(C64Params p) {
             const bool ok = sidx < XR * RB * 8 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
             const unsigned off = ok ? (unsigned)gy * row_bytes + (unsigned)gx * p.in_cs * 2 + chb * 16 : OOB_COL;
             vb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 0));
-            lb[i] = (row * ROWP + col) * 128 + ((chb ^ ((col >> 1) & 7)) << 4);
+            lb[i] = (row * ROWP + col) * 128 + ((chb ^ c64_key(col)) << 4);
         }
 #pragma unroll
         for (int g = 0; g < NA; ++g)

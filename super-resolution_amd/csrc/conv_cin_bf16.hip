@@ -127,7 +127,7 @@ __global__ __launch_bounds__(NW * 64, WGPC) void conv_cin_kernel(CinParams p) {
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
             const int P = prow[k] * ROWP + pcol[k] + pl + dx;
-            boff[k][dx] = P * 128 + ((q ^ ((P >> 1) & 7)) << 4);
+            boff[k][dx] = P * 128 + ((q ^ c64_key(P)) << 4);
         }
 
     f32x4 acc[PT][NCT];
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(NW * 64, WGPC) void conv_cin_kernel(CinParams p) {
                 u32x4 z = v[it];
                 if (!ok) z = (u32x4){0u, 0u, 0u, 0u};
                 const int P = row * ROWP + col;
-                if (idx < NCH) *(u32x4*)(lds + P * 128 + ((ch ^ ((P >> 1) & 7)) << 4)) = z;
+                if (idx < NCH) *(u32x4*)(lds + P * 128 + ((ch ^ c64_key(P)) << 4)) = z;
             }
         }
         // tile written; the loads' vmcnt(0) also retired every weight tap issued so far

@@ -35,8 +35,18 @@ struct ResBlockParams {
     int N, H, W, in_cs;
     int tiles_x, tiles_y;
     int res_is_x;   // the residual is the block's own input (same pointer, 64-channel pixels): it can come from the LDS tile
-    int dbg;  // ablation (SRMI_DBG env, investigation only): 1 skip staging, 2 skip conv1 K loop, 8 skip conv2 K loop, 4 skip epilogue, 16 skip T write
+    int dbg;  // ablation (SRMI_DBG env, ablation build only): 1 skip staging, 2 skip conv1 K loop, 8 skip conv2 K loop, 4 skip epilogue, 16 skip T write
+    int exp;  // scheduling experiments (SRMI_EXP env, ablation build only; results stay correct)
+#ifdef SRMI_ABLATE
+    unsigned long long* stamps;   // per launch slot: [workgroup][8] s_memrealtime stamps (100 MHz), or nullptr
+#endif
 };
+
+#ifdef SRMI_ABLATE
+#define RB_STAMP(i) do { if (p.stamps) { st[i] = __builtin_amdgcn_s_memrealtime(); ck[i] = __builtin_amdgcn_s_memtime(); } } while (0)
+#else
+#define RB_STAMP(i) do { } while (0)
+#endif
 
 constexpr int RB_STEP_BYTES = 4096;   // one K-step: 4 channel tiles x 64 lanes x 16 B
 
@@ -58,7 +68,7 @@ __global__ __launch_bounds__(NW * 64, WGPC) void resblock_c64_kernel(ResBlockPar
                                                      // the swizzle key (col >> 1) & 7 is the same for every row (tap dy = +pitch)
     static_assert(ROWP % 2 == 0, "pixel pairs must not straddle rows");
     // swizzle key of LDS pixel P = row * ROWP + col (the P form keeps fewer values alive when the pitch allows it)
-    auto swz = [](int P, int col) { return ROWP % 16 == 0 ? (P >> 1) & 7 : (col >> 1) & 7; };
+    auto swz = [](int P, int col) { return ROWP % 8 == 0 ? c64_key(P) : c64_key(col); };
     constexpr int IN_BYTES = XR * ROWP * 128;
     constexpr int NT1 = (TR * TC + 15) / 16;         // flattened 16-pixel tiles of the T region
     constexpr int PT1 = (NT1 + NW - 1) / NW;
@@ -73,6 +83,10 @@ __global__ __launch_bounds__(NW * 64, WGPC) void resblock_c64_kernel(ResBlockPar
     float* const par = (float*)(lds + IN_BYTES + SLOTS * SLOT_BYTES);
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef SRMI_ABLATE
+    unsigned long long st[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ck[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    RB_STAMP(0);
 
     // XCD-aware tile order: consecutive workgroup ids go round-robin to the 8 XCDs (one L2 each), so give each
     // XCD a CONTIGUOUS run of tiles - vertically adjacent tiles then share their halo rows through one L2.
@@ -83,6 +97,20 @@ __global__ __launch_bounds__(NW * 64, WGPC) void resblock_c64_kernel(ResBlockPar
     const int n = b / p.tiles_y;
     const int y0 = ty * TH, x0 = tx * TW;
     const int kdbg = p.dbg;                   // phase-ablation switches (SRMI_DBG, investigation only)
+    {   // SRMI_EXP (ablation build): de-phase the two workgroups that share a CU - one gets instruction priority, the other
+        // may start its loads late
+        const int ex = p.exp;
+        if (ex & 6) {
+            const bool low = (ex & 2) ? blockIdx.x >= (gridDim.x >> 1) : ((blockIdx.x >> 3) & 1) != 0;
+            if (low) {
+                __builtin_amdgcn_s_setprio(0);
+                if (ex & 8) __builtin_amdgcn_s_sleep(40);
+                if (ex & 16) __builtin_amdgcn_s_sleep(80);
+            } else {
+                __builtin_amdgcn_s_setprio(3);
+            }
+        }
+    }
     const ResBlockVar& V = p.v;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -160,7 +188,7 @@ __global__ __launch_bounds__(NW * 64, WGPC) void resblock_c64_kernel(ResBlockPar
         for (int g = 0; g < NA; ++g) {
             const int col = g * CPT + c0, gx = x0 - 2 + col;
             const unsigned coff = (gx >= 0 && gx < p.W) ? (unsigned)gx * p.in_cs * 2 + ch * 16 : OOB_COL;
-            la[g] = col * 128 + ((ch ^ ((col >> 1) & 7)) << 4);
+            la[g] = col * 128 + ((ch ^ c64_key(col)) << 4);
 #pragma unroll
             for (int row = 0; row < XR; ++row) {
                 const int gy = y0 - 2 + row;                               // wave-uniform
@@ -177,7 +205,7 @@ __global__ __launch_bounds__(NW * 64, WGPC) void resblock_c64_kernel(ResBlockPar
             const bool ok = sidx < XR * RB * 8 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
             const unsigned off = ok ? (unsigned)gy * row_bytes + (unsigned)gx * p.in_cs * 2 + chb * 16 : OOB_COL;
             vb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 0));
-            lb[i] = (row * ROWP + col) * 128 + ((chb ^ ((col >> 1) & 7)) << 4);
+            lb[i] = (row * ROWP + col) * 128 + ((chb ^ c64_key(col)) << 4);
         }
 #pragma unroll
         for (int g = 0; g < NA; ++g)
@@ -187,10 +215,13 @@ __global__ __launch_bounds__(NW * 64, WGPC) void resblock_c64_kernel(ResBlockPar
         for (int i = 0; i < NB; ++i)
             if (tid + i * NTH < XR * RB * 8) *(u32x4*)(lds + lb[i]) = vb[i];
     }
+    RB_STAMP(1);
     c64_params_store(par, pregs1, 1, tid);
     c64_params_store(par + 192, pregs2, 1, tid);
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // also retires weight steps 0..2
+    RB_STAMP(2);
     __builtin_amdgcn_s_barrier();
+    RB_STAMP(3);
 
     // one K-step hand-off: step g+1 landed (own copy: counted vmcnt, others': barrier); slot of step g-1
     // is free (its fragments were consumed by the MFMAs of step g-1, which every wave has issued).
@@ -211,12 +242,22 @@ __global__ __launch_bounds__(NW * 64, WGPC) void resblock_c64_kernel(ResBlockPar
     // LDS address of the fragments of K-step g
     auto frag = [&](int g) { return wring + ((g / KS) % SLOTS) * SLOT_BYTES + (g % KS) * RB_STEP_BYTES + lane * 16; };
 
+    // Tiles per wave.  With two waves per SIMD (waves w and w + NW/2 share one) the SIMD's MFMA time per K-step is the SUM of
+    // its two waves' tile counts, so the two halves of the workgroup may take different counts: 44 conv-1 tiles = 4 x (6 + 5)
+    // and 36 conv-2 tiles = 4 x (5 + 4) fill every slot, where 8 x 6 and 8 x 5 left 4 + 4 of 88 slots recomputing a
+    // neighbour's tile (9 % of the MFMAs - and at the 1.69 GHz the matrix cores are power-limited to, wasted MFMAs also
+    // cost clock).  Two instantiations of the phases, chosen by a wave-uniform branch; both execute the same barriers.
+    constexpr bool SPLIT1 = NW == 8 && NT1 <= (NW / 2) * (2 * PT1 - 1);
+    constexpr bool SPLIT2 = NW == 8 && NPT2 <= (NW / 2) * (2 * PT2 - 1);
+    constexpr int PT1B = SPLIT1 ? PT1 - 1 : PT1, PT2B = SPLIT2 ? PT2 - 1 : PT2;
+    auto body = [&](auto P1, auto P2, const int t1base, const int t2base) {
+    constexpr int PT1c = decltype(P1)::value, PT2c = decltype(P2)::value;
     // ================= phase 1: conv1 over the flattened T region =================================
-    int boff1[PT1][3];
+    int boff1[PT1c][3];
     unsigned inside = 0;     // bit k: this lane's pixel of tile k lies inside the image (else T = 0: conv2's zero padding)
 #pragma unroll
-    for (int k = 0; k < PT1; ++k) {
-        const int pix = min((wave * PT1 + k) * 16 + pl, TR * TC - 1);   // padding tiles recompute the last pixel
+    for (int k = 0; k < PT1c; ++k) {
+        const int pix = min((t1base + k) * 16 + pl, TR * TC - 1);   // padding tiles recompute the last pixel
         const int ti = pix / TC, tj = pix - ti * TC;
         const int gy = y0 - 1 + ti, gx = x0 - 1 + tj;
         inside |= (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? 1u << k : 0u;
@@ -226,18 +267,18 @@ __global__ __launch_bounds__(NW * 64, WGPC) void resblock_c64_kernel(ResBlockPar
             boff1[k][dx] = P * 128 + ((q ^ swz(P, tj + dx)) << 4);
         }
     }
-    asm volatile("" : "+v"(inside));      // materialise the mask HERE (hipcc would sink it below the K loop and keep its 2*PT1 inputs alive)
+    asm volatile("" : "+v"(inside));      // materialise the mask HERE (hipcc would sink it below the K loop and keep its 2*PT1c inputs alive)
     {
-        f32x4 acc[PT1][4];
+        f32x4 acc[PT1c][4];
 #pragma unroll
-        for (int k = 0; k < PT1; ++k)
+        for (int k = 0; k < PT1c; ++k)
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[k][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        bf16x8 afr[2][4], bfr[2][PT1];
+        bf16x8 afr[2][4], bfr[2][PT1c];
 #pragma unroll
         for (int t = 0; t < 4; ++t) afr[0][t] = *(const bf16x8*)(wring + lane * 16 + t * 1024);
 #pragma unroll
-        for (int k = 0; k < PT1; ++k) bfr[0][k] = *(const bf16x8*)(lds + boff1[k][0]);
+        for (int k = 0; k < PT1c; ++k) bfr[0][k] = *(const bf16x8*)(lds + boff1[k][0]);
         if (!(kdbg & 2))
 #pragma unroll
         for (int j = 0; j < 18; ++j) {
@@ -250,32 +291,33 @@ __global__ __launch_bounds__(NW * 64, WGPC) void resblock_c64_kernel(ResBlockPar
                     const int tapn = (j + 1) >> 1, halfn = (j + 1) & 1;
                     const int dyn = tapn / 3, dxn = tapn - 3 * dyn;
 #pragma unroll
-                    for (int k = 0; k < PT1; ++k)
+                    for (int k = 0; k < PT1c; ++k)
                         bfr[(j + 1) & 1][k] =
                             *(const bf16x8*)(lds + ((boff1[k][dxn] ^ (halfn << 6)) + dyn * (ROWP * 128)));
                 }
             }
 #pragma unroll
-            for (int k = 0; k < PT1; ++k)
+            for (int k = 0; k < PT1c; ++k)
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                     acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[j & 1][t], bfr[j & 1][k], acc[k][t], 0, 0, 0);
-            if (j + 1 < 18) sched_interleave<0, 4 + PT1, 4 * PT1>();
+            if (j + 1 < 18) sched_interleave<0, 4 + PT1c, 4 * PT1c>();
         }
 
+        RB_STAMP(4);
         // ---- phase 2: T = act(affine1(acc)) as bf16 over the x tile (zero outside the image) ----
         // The residual IS the centre of the x tile: take it from LDS now (the operand fragments are dead, T is about
-        // to overwrite the tile) instead of re-reading it from L2 in the epilogue.  PT2 * 8 registers, kept across
+        // to overwrite the tile) instead of re-reading it from L2 in the epilogue.  PT2c * 8 registers, kept across
         // conv2; worth it while they fit (8-wave variant, small tile) - at 9 tiles per wave hipcc spills them.
-        constexpr bool RES_LDS = PT2 * 8 <= 40;
-        u32x4 rpre[RES_LDS ? PT2 : 1][2];
+        constexpr bool RES_LDS = PT2c * 8 <= 40;
+        u32x4 rpre[RES_LDS ? PT2c : 1][2];
         if constexpr (RES_LDS) {
             if (p.res_is_x) {
                 int opr;      // (opaque zero in the address: keeps these loads where they are written)
                 asm volatile("v_mov_b32 %0, 0" : "=v"(opr));
 #pragma unroll
-                for (int k = 0; k < PT2; ++k) {
-                    const int t = min(wave * PT2 + k, NPT2 - 1);
+                for (int k = 0; k < PT2c; ++k) {
+                    const int t = min(t2base + k, NPT2 - 1);
                     const int col = (t % TWT) * 16 + pl + 2 + opr;
                     const int P = (t / TWT + 2) * ROWP + col;
                     const int a0 = P * 128 + ((q ^ swz(P, col)) << 4);
@@ -308,7 +350,7 @@ __global__ __launch_bounds__(NW * 64, WGPC) void resblock_c64_kernel(ResBlockPar
                 }
             }
 #pragma unroll
-            for (int k = 0; k < PT1; ++k) {
+            for (int k = 0; k < PT1c; ++k) {
                 const unsigned keep = (unsigned)((int)(inside << (31 - k)) >> 31);
                 u32x4 o;
 #pragma unroll
@@ -331,17 +373,18 @@ __global__ __launch_bounds__(NW * 64, WGPC) void resblock_c64_kernel(ResBlockPar
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();           // T complete
+        RB_STAMP(5);
         // (the first weight fragments of conv2 were prefetched into afr[0] during step 17: 18 & 1 == 0)
         // ================= phase 3: conv2 from T ==================================================
-        int prow[PT2], pcol[PT2];
-        int boff2[PT2][3];
+        int prow[PT2c], pcol[PT2c];
+        int boff2[PT2c][3];
         // opaque zero: keeps hipcc from hoisting this phase's address arithmetic above conv1's K loop, where it would
         // be spilled to scratch (the loop runs at the register limit)
         int opaque0;
         asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));
 #pragma unroll
-        for (int k = 0; k < PT2; ++k) {
-            const int t = min(wave * PT2 + k, NPT2 - 1);
+        for (int k = 0; k < PT2c; ++k) {
+            const int t = min(t2base + k, NPT2 - 1);
             prow[k] = t / TWT;
             pcol[k] = (t - prow[k] * TWT) * 16;
 #pragma unroll
@@ -350,16 +393,16 @@ __global__ __launch_bounds__(NW * 64, WGPC) void resblock_c64_kernel(ResBlockPar
                 const int P = prow[k] * ROWP + col;
                 boff2[k][dx] = P * 128 + ((q ^ swz(P, col)) << 4);
             }
-            if (wave * PT2 + k >= NPT2) prow[k] = 1 << 20;     // padding tile: the epilogue's bounds check drops it
+            if (t2base + k >= NPT2) prow[k] = 1 << 20;     // padding tile: the epilogue's bounds check drops it
         }
-        f32x4 acc2[PT2][4];
+        f32x4 acc2[PT2c][4];
 #pragma unroll
-        for (int k = 0; k < PT2; ++k)
+        for (int k = 0; k < PT2c; ++k)
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc2[k][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        bf16x8 bfr2[2][PT2];
+        bf16x8 bfr2[2][PT2c];
 #pragma unroll
-        for (int k = 0; k < PT2; ++k) bfr2[0][k] = *(const bf16x8*)(lds + boff2[k][0]);
+        for (int k = 0; k < PT2c; ++k) bfr2[0][k] = *(const bf16x8*)(lds + boff2[k][0]);
         if (!(kdbg & 8))
 #pragma unroll
         for (int j = 0; j < 18; ++j) {
@@ -372,27 +415,70 @@ __global__ __launch_bounds__(NW * 64, WGPC) void resblock_c64_kernel(ResBlockPar
                 const int tapn = (j + 1) >> 1, halfn = (j + 1) & 1;
                 const int dyn = tapn / 3, dxn = tapn - 3 * dyn;
 #pragma unroll
-                for (int k = 0; k < PT2; ++k)
+                for (int k = 0; k < PT2c; ++k)
                     bfr2[(j + 1) & 1][k] =
                         *(const bf16x8*)(lds + ((boff2[k][dxn] ^ (halfn << 6)) + dyn * (ROWP * 128)));
             }
 #pragma unroll
-            for (int k = 0; k < PT2; ++k)
+            for (int k = 0; k < PT2c; ++k)
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                     acc2[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[j & 1][t], bfr2[j & 1][k], acc2[k][t], 0, 0, 0);
-            if (j + 1 < 18) sched_interleave<0, 4 + PT2, 4 * PT2>();
+            if (j + 1 < 18) sched_interleave<0, 4 + PT2c, 4 * PT2c>();
         }
+        RB_STAMP(6);
         if (!(kdbg & 4)) {
             if constexpr (RES_LDS) {
-                if (p.res_is_x) c64_epilogue<PT2, true>(acc2, par + 192, V.epi2, 0, n, y0, x0, prow, pcol, pl, q, rpre);
-                else c64_epilogue<PT2>(acc2, par + 192, V.epi2, 0, n, y0, x0, prow, pcol, pl, q);
+                if (p.res_is_x) c64_epilogue<PT2c, true>(acc2, par + 192, V.epi2, 0, n, y0, x0, prow, pcol, pl, q, rpre);
+                else c64_epilogue<PT2c>(acc2, par + 192, V.epi2, 0, n, y0, x0, prow, pcol, pl, q);
             } else {
-                c64_epilogue<PT2>(acc2, par + 192, V.epi2, 0, n, y0, x0, prow, pcol, pl, q);
+                c64_epilogue<PT2c>(acc2, par + 192, V.epi2, 0, n, y0, x0, prow, pcol, pl, q);
             }
         }
+#ifdef SRMI_ABLATE
+        if (p.stamps) {
+            st[7] = __builtin_amdgcn_s_memrealtime(); ck[7] = __builtin_amdgcn_s_memtime();
+            if (lane == 0 && wave == 0) {      // row 0: real time (100 MHz), row 1: shader clock counter
+                unsigned long long* d = p.stamps + (size_t)blockIdx.x * 16;
+#pragma unroll
+                for (int i = 0; i < 8; ++i) { d[i] = st[i]; d[8 + i] = ck[i]; }
+            }
+        }
+#endif
+    }
+    };
+    if constexpr (SPLIT1 || SPLIT2) {
+        if (wave < NW / 2) body(std::integral_constant<int, PT1>{}, std::integral_constant<int, PT2>{}, wave * PT1, wave * PT2);
+        else body(std::integral_constant<int, PT1B>{}, std::integral_constant<int, PT2B>{},
+                  (NW / 2) * PT1 + (wave - NW / 2) * PT1B, (NW / 2) * PT2 + (wave - NW / 2) * PT2B);
+    } else {
+        body(std::integral_constant<int, PT1>{}, std::integral_constant<int, PT2>{}, wave * PT1, wave * PT2);
     }
 }
+
+#ifdef SRMI_ABLATE
+// stamp buffer of the ablation build: SRMI_STAMPS=<launches> allocates [launches][1024 workgroups][2 waves][8] u64 at the first
+// launch; srmi_dbg_resblock_stamps copies it to the host.
+static unsigned long long* g_stamps = nullptr;
+static int g_stamp_slots = 0, g_stamp_next = 0;
+static unsigned long long* next_stamp_slot(unsigned nb) {
+    static const int want = [] { const char* e = getenv("SRMI_STAMPS"); return e ? atoi(e) : 0; }();
+    if (!want || nb > 1024) return nullptr;
+    if (!g_stamps) {
+        if (hipMalloc((void**)&g_stamps, (size_t)want * 1024 * 16 * 8) != hipSuccess) return nullptr;
+        (void)hipMemset(g_stamps, 0, (size_t)want * 1024 * 16 * 8);
+        g_stamp_slots = want;
+    }
+    if (g_stamp_next >= g_stamp_slots) return nullptr;
+    return g_stamps + (size_t)(g_stamp_next++) * 1024 * 16;
+}
+extern "C" int srmi_dbg_resblock_stamps(void* host_dst, size_t bytes, int* launches, int reset) {
+    if (launches) *launches = g_stamp_next;
+    if (g_stamps && host_dst) (void)hipMemcpy(host_dst, g_stamps, bytes, hipMemcpyDeviceToHost);
+    if (reset) g_stamp_next = 0;
+    return 0;
+}
+#endif
 
 bool resblock_supported(const srmi_conv_desc& d1, const srmi_conv_desc& d2) {
     if (!c64_supported(d1) || !c64_supported(d2)) return false;
@@ -431,6 +517,10 @@ int resblock_launch(const srmi_conv_args& a1, const srmi_conv_args& a2, hipStrea
     p.v.epi2.act = d2.act; p.v.epi2.act_param = d2.act_param; p.v.epi2.alpha_pc = d2.alpha_per_channel;
     p.N = d1.N; p.H = d1.H; p.W = d1.W; p.in_cs = d1.in_cstride ? d1.in_cstride : 64;
     p.dbg = dbg_flags();
+    p.exp = exp_flags();
+#ifdef SRMI_ABLATE
+    p.stamps = nullptr;
+#endif
     if (p.dbg & 512) p.v.epi2.res = nullptr;     // ablation: no residual read
     p.res_is_x = p.v.epi2.res != nullptr && (const void*)p.v.epi2.res == (const void*)p.v.x && p.in_cs == 64 && !(p.dbg & 2048);
     if (p.dbg & 1024) p.v.epi2.H = 0;            // ablation: epilogue arithmetic only (every pixel fails the bounds check: no loads, no stores)
@@ -443,7 +533,7 @@ int resblock_launch(const srmi_conv_args& a1, const srmi_conv_args& a2, hipStrea
     const long long nb48 = (long long)d1.N * ((d1.W + 47) / 48) * ((d1.H + 11) / 12);
     const bool t12 = big && d1.H >= 12 && !(p.dbg & (1 << 23)) &&
                      ((nb48 + 255) / 256) * (48 + 40) <= ((nb96 + 255) / 256) * (56 + 40);
-    if (big && (p.dbg & 4096)) {        // 6 x 48 tiles, two workgroups per CU
+    if (big && ((p.dbg & 4096) || (p.exp & 1))) {        // 6 x 48 tiles, two workgroups per CU
         p.tiles_x = (d1.W + 47) / 48; p.tiles_y = (d1.H + 5) / 6;
         const long long nb = (long long)d1.N * p.tiles_x * p.tiles_y;
         if (nb > 0x7fffffffLL) { set_error("resblock_bf16: grid too large"); return SRMI_EINVAL; }
@@ -455,7 +545,12 @@ int resblock_launch(const srmi_conv_args& a1, const srmi_conv_args& a2, hipStrea
         // at this tile: 157 KB) - 29.4 vs 29.75 us per launch in three alternating runs; SRMI_DBG bit 22: the K-step ring
         // (four tap slots with an 8-pixel pitch, 149 KB: 29.0 vs 28.2 us - the narrower pitch costs more than the deeper ring gains)
         if (p.dbg & (1 << 22)) hipLaunchKernelGGL((resblock_c64_kernel<12, 3, 8, 4, 1, 1>), dim3((unsigned)nb48), dim3(512), 0, s, p);
-        else hipLaunchKernelGGL((resblock_c64_kernel<12, 3, 8, 3, 1, 2>), dim3((unsigned)nb48), dim3(512), 0, s, p);
+        else {
+#ifdef SRMI_ABLATE
+            p.stamps = next_stamp_slot((unsigned)nb48);
+#endif
+            hipLaunchKernelGGL((resblock_c64_kernel<12, 3, 8, 3, 1, 2>), dim3((unsigned)nb48), dim3(512), 0, s, p);
+        }
     } else if (big) {
         p.tiles_x = (d1.W + 95) / 96; p.tiles_y = (d1.H + 5) / 6;
         const long long nb = (long long)d1.N * p.tiles_x * p.tiles_y;

@@ -22,7 +22,7 @@
 
 #include <type_traits>
 
-#include "common.h"
+#include "c64_common.h"
 
 namespace srmi {
 
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256, 2) void conv_thin_kernel(ThinParams p) {
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
         const int pix = 8 * (wave + 4 * i) + (lane >> 3);        // DMA instruction wave+4i covers slot pixels 8*(wave+4i)..+7
-        const int ch = (lane & 7) ^ ((pix >> 1) & 7);
+        const int ch = (lane & 7) ^ c64_key(pix);
         const int gx = x0 - 1 + pix;
         coloff[i] = (pix < 66 && gx >= 0 && gx < p.W) ? ((long long)gx * p.in_cs + ch * 8) * 2 : -1;
     }
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256, 2) void conv_thin_kernel(ThinParams p) {
 #pragma unroll
     for (int dx = 0; dx < 3; ++dx) {
         const int P = wave * 16 + pl + dx;
-        boff[dx] = P * 128 + ((q ^ ((P >> 1) & 7)) << 4);
+        boff[dx] = P * 128 + ((q ^ c64_key(P)) << 4);
     }
 
     // epilogue constants: MFMA rows 0..3 (lanes q == 0) are output channels 0..3

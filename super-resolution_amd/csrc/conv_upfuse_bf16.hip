@@ -153,7 +153,7 @@ __global__ __launch_bounds__(NW * 64, 1) void upfuse_kernel(UpFuseParams p) {
             const bool ok = sidx < NV && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
             const unsigned off = ok ? (unsigned)gy * row_bytes + (unsigned)gx * p.in_cs * 2 + chb * 16 : OOB;
             vb[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(xres, off, 0, 0));
-            lb[i] = (row * ROWP + col) * 128 + ((chb ^ ((col >> 1) & 7)) << 4);
+            lb[i] = (row * ROWP + col) * 128 + ((chb ^ c64_key(col)) << 4);
         }
         for (int i = tid; i < OB_BYTES / 16; i += NTH) ((u32x4*)obuf)[i] = (u32x4){0u, 0u, 0u, 0u};
 #pragma unroll
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(NW * 64, 1) void upfuse_kernel(UpFuseParams p) {
 #pragma unroll
             for (int dx = 0; dx < 3; ++dx) {
                 const int col = bcol[k] + 1 - sj + dx;
-                boff[k][dx] = brow[k] + (1 - si) * (ROWP * 128) + col * 128 + ((q ^ ((col >> 1) & 7)) << 4);
+                boff[k][dx] = brow[k] + (1 - si) * (ROWP * 128) + col * 128 + ((q ^ c64_key(col)) << 4);
             }
 
         bf16x8 afr[2][4], bfr[2][PT];
