@@ -18,6 +18,14 @@ Extra objects on the JSON line:
                  bf16 MFMA peak; its time is measured with HIP events on the launch stream.
   cpu_baseline - the oracle (plain torch.nn.functional restatement, pinned to the reference) timed on
                  this box's host cores, rank 0, N=1 only.
+  secondary    - N=1 only: the other BASELINE configurations, each a sub-second leg measured in this same run
+                 (tools/bench_variants.py, tools/bench_train_step.py): cfg2 SRCNN (both parameterisations, per-layer
+                 HBM fraction), cfg3 SRGAN training step (ms/step, host-enqueue ms, f32-equivalent TFLOP/s), cfg4 RRDB-23
+                 bf16 (ms, TFLOP/s, fraction of peak), cfg5 tiled 960x540 frame (ms/frame, MP/s).  --no-secondary skips it.
+
+`--workload cfg5` (with any --gpus N) switches the timed step to BASELINE config 5: a stream of 960x540 frames, each cut into
+8 LR tiles of 270x240 + 8 px halo that are dealt round-robin to the ranks (srmi.tiling.shard, no collective); a step =
+one frame; value = useful output MP/s (halo pixels not counted); total work is fixed as N grows ("scaling": "strong").
 """
 from __future__ import annotations
 
@@ -39,6 +47,7 @@ PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chi
 PEAK_F32_MFMA_TFLOPS = 157.3  # exact-f32 MFMA
 BATCH, LR_H, LR_W, NUM_BLOCK = 16, 96, 96, 16
 FLOP_PER_OUT_PIXEL = 249_624  # SURVEY App. A / BASELINE.md section 4 (conv MACs x 2 only)
+PROFILE_TAG = "r3"            # profiles/<tag>_bench_kernel_stats.csv, <tag>_pmc_traffic.json: the committed rocprofv3 runs
 
 
 def conv_flops(d):
@@ -238,6 +247,71 @@ def cpu_baseline(threads, sd, x, info=None):
     return res
 
 
+def secondary(dev):
+    """The other BASELINE configurations on this GPU, each leg a fraction of a second of device time.
+    A leg that fails reports its error instead of taking the headline line down with it."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_train_step as T
+    import bench_variants as V
+    out = {}
+
+    def leg(name, fn):
+        try:
+            out[name] = fn()
+        except Exception as e:     # noqa: BLE001
+            out[name] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    leg("cfg2_srcnn", lambda: V.cfg2(steps=20, warmup=3))
+    leg("cfg3_srgan_train_step", lambda: T.cfg3(steps=10, warmup=3, dev=dev))
+    leg("cfg4_rrdb23", lambda: V.cfg4(steps=10, warmup=3))
+    leg("cfg5_tiled_960x540", lambda: V.cfg5(steps=20, warmup=3))
+    return out
+
+
+def run_cfg5(args, dev, dist, rank, world):
+    """BASELINE config 5 as the timed step: frames of 960x540 -> 3840x2160, tiles sharded over the ranks."""
+    from srmi.srgan_model import Generator
+    from srmi.tiling import max_over_ranks, sr_tiled
+    gen = Generator(num_block=NUM_BLOCK)
+    gen.load_state_dict(synthetic_state(gen, seed=0))
+    gen = gen.to(dev).eval().set_compute(args.compute)
+    frame = torch.empty((1, 3, 540, 960)).uniform_(-1.0, 1.0, generator=torch.Generator().manual_seed(1)).to(dev)
+    out = torch.zeros((1, 3, 2160, 3840), dtype=torch.float32, device=dev)
+    steps = max(args.steps, 32)                      # a stream of >= 32 frames (SURVEY 8d2)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            sr_tiled(gen, frame, tile=(270, 240), halo=8, rank=rank, world=world, out=out)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            _, ntiles = sr_tiled(gen, frame, tile=(270, 240), halo=8, rank=rank, world=world, out=out)
+        barrier()
+        elapsed = time.perf_counter() - t0
+    elapsed = max_over_ranks(elapsed, dist, dev)
+    if rank != 0:
+        return None
+    mp_frame = 3840 * 2160 / 1e6
+    value = mp_frame * steps / elapsed
+    tf = value * 1e6 * FLOP_PER_OUT_PIXEL / 1e12
+    return {"metric": "x4 SR output megapixels/sec (whole node)", "value": round(value, 2), "unit": "MP/s",
+            "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "bf16" if args.compute == "bf16" else "f32", "data": "synthetic",
+            "config": {"workload": "cfg5: tiled SRResNet x4 inference, 960x540 -> 3840x2160 frames, 8 LR tiles of 270x240 + 8 px "
+                                   "halo per frame dealt round-robin to the ranks, no collective; useful pixels only",
+                       "tiles_per_frame": 8, "tiles_rank0": ntiles, "parallelism": f"tile-sharded x{world}, no collective"},
+            "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS * world, "unit": "TFLOP/s",
+                         "frac": round(tf / (PEAK_BF16_TFLOPS * world), 4), "traffic": None,
+                         "note": "whole-job useful FLOPs (249,624 per output pixel) / time; the per-kernel roofline is on the cfg1 line"}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -245,6 +319,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--compute", default="bf16", choices=["bf16", "fp32"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the cfg2..cfg5 legs of the N=1 line")
+    ap.add_argument("--workload", default="cfg1", choices=["cfg1", "cfg5"])
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -278,6 +354,15 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
+
+    if args.workload == "cfg5":
+        result = run_cfg5(args, dev, dist, rank, world)
+        if dist is not None:
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps(result), flush=True)
+        return
 
     gen, x, sd_cpu, x_cpu = build_generator(dev, args.compute)
 
@@ -330,7 +415,7 @@ def main():
         trace_us = None      # average duration of the dominant kernel in the committed kernel trace (profiles/)
         try:
             import csv
-            for r in csv.DictReader(open(os.path.join(ROOT, "profiles", "r2_bench_kernel_stats.csv"))):
+            for r in csv.DictReader(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_bench_kernel_stats.csv"))):
                 if "resblock_c64_kernel" in r["Name"] and args.compute == "bf16":
                     trace_us = round(float(r["AverageNs"]) / 1e3, 2)
                     break
@@ -338,18 +423,20 @@ def main():
             trace_us = None
         traffic = None       # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_summary.py)
         try:
-            pm = json.load(open(os.path.join(ROOT, "profiles", "r2_pmc_traffic.json")))["kernels"]
+            pm = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_traffic.json")))["kernels"]
             traffic = next(v["hbm_bytes"] for k, v in pm.items() if "resblock_c64_kernel" in k) if args.compute == "bf16" else None
         except Exception:
             traffic = None
         roofline = {"bound": "mfma", "kernel": "resblock_c64_kernel" if args.compute == "bf16" else "conv_generic_kernel",
                     "launches_per_step": n_dom, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
+                    "traffic_source": f"profiles/{PROFILE_TAG}_pmc_traffic.json: committed rocprofv3 --pmc passes of this command "
+                                      "(FETCH_SIZE x2 + WRITE_SIZE per launch); NOT measured in this run (PMC needs the profiler)",
                     "avg_launch_us": round(t_dom / n_dom * 1e6, 2),
                     # average kernel duration in the committed rocprofv3 kernel trace of this command (kernels of consecutive
                     # launches overlap by ~2 us there: the next one's waves start while the previous one's stores drain)
-                    "kernel_trace_avg_us": trace_us,
-                    "frac_by_kernel_trace": round(flops / n_dom / (trace_us * 1e-6) / 1e12 / peak, 4) if trace_us else None,
+                    "kernel_trace_avg_us_from_committed_profile": trace_us,
+                    "frac_by_committed_kernel_trace": round(flops / n_dom / (trace_us * 1e-6) / 1e12 / peak, 4) if trace_us else None,
                     "flops_per_launch": flops / n_dom,
                     "algorithmic_bytes_per_launch": 2 * BATCH * LR_H * LR_W * 64 * 2,
                     "mfma_family_tflops": round(f_fam / t_fam / 1e12, 2),
@@ -359,8 +446,8 @@ def main():
                     "method": "HIP events (torch's current stream = the launch stream) around every launch (one pair around each run of "
                               "identical consecutive launches, e.g. the 16 ResBlocks: time / run length) of "
                               "instrumented forwards run right after the timed region, same process/data; achieved = "
-                              "algorithmic conv FLOPs of the kernel's launches / their event time; traffic = FETCH_SIZE x2 "
-                              "+ WRITE_SIZE per launch from separate rocprofv3 --pmc passes (profiles/r2_pmc_traffic.json)"}
+                              "algorithmic conv FLOPs of the kernel's launches / their event time (measured live); traffic and "
+                              "kernel_trace_avg_us_from_committed_profile are read from profiles/ (see traffic_source)"}
         result = {
             "metric": "x4 SR output megapixels/sec (whole node)", "value": round(value, 2), "unit": "MP/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
@@ -375,6 +462,8 @@ def main():
         if world == 1 and args.compute == "bf16":
             del gen                                   # plan buffers of the bf16 model are no longer needed
             result["fp32_path"] = fp32_path(dev)
+        if world == 1 and args.compute == "bf16" and not args.no_secondary:
+            result["secondary"] = secondary(dev)
         if world == 1 and not args.no_cpu_baseline:
             info = host_cpu_info()
             result["cpu_baseline"] = cpu_baseline(baseline_threads(info), sd_cpu, x_cpu, info)

@@ -13,7 +13,8 @@ The frozen VGG has no gradients and takes no part.
 
 Two forms:
   * `average_gradients(params)` after `backward()` - the two-line change to the reference loop shown above;
-  * `GradientAverager(params)` - persistent flat buckets filled by post-accumulate-grad hooks WHILE backward runs:
+  * `GradientAverager(params)` - persistent flat buckets filled by post-accumulate-grad hooks WHILE the model's own
+    backward runs (`with avg.sync(): loss.backward()`; the hooks ignore every other backward):
     a bucket's all-reduce starts as soon as its last gradient has been produced (the discriminator's 75 MB Linear
     gradient reduces while the conv layers' backward is still computing), `.grad` becomes a view of the bucket (no
     copy back), and `finish()` before `optim.step()` only waits and scales.  One pass over the gradients instead of
@@ -107,25 +108,39 @@ def broadcast_parameters(module, src=0, group=None):
 class GradientAverager:
     """Overlapped form of `average_gradients` for one model (see the module docstring).
 
-        avg = GradientAverager(discriminator.parameters())
+        d_avg = GradientAverager(discriminator.parameters())
+        g_avg = GradientAverager(generator.parameters())
         ...
-        d_loss.backward()          # hooks fill the buckets and launch their all-reduces as backward proceeds
-        avg.finish()               # wait + scale by 1/world; p.grad is now a view of its bucket
-        d_optim.step()
+        with d_avg.sync():         # P/mode.py:160-161
+            d_loss.backward()      # hooks fill the buckets and launch their all-reduces as backward proceeds
+        d_optim.step()             # leaving the block waited and scaled by 1/world; p.grad is a view of its bucket
+        ...
+        with g_avg.sync():         # P/mode.py:178-179
+            g_loss.backward()
+        g_optim.step()
 
+    The hooks only act while the averager is ARMED (`begin()` ... `finish()`, or the `sync()` block).  That matters in
+    the reference's SRGAN iteration: `d_loss.backward()` also reaches the generator's parameters (the generator output
+    is not detached, P/mode.py:149-160) and `g_loss.backward()` reaches the discriminator's (:165,178); those foreign
+    gradients are thrown away by the next `zero_grad()` and must neither be copied into a bucket nor start an
+    all-reduce.  A disarmed hook does nothing at all.
+
+    Per-parameter ready flags (not a counter): a bucket's all-reduce starts when every one of its parameters has
+    reported in this armed backward.  `finish()` waits on every outstanding handle before a bucket can be reused.
     Works with the reference loop's `zero_grad()` (grads set to None): each backward hands the hook a fresh gradient,
     which is copied into the bucket once.  With world size 1 (or no process group) it does nothing."""
 
     def __init__(self, params, group=None, max_buckets=4):
         self.group = group
         self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        self.armed = False
         self.params = []
         seen = set()
         for p in params:
             if p.requires_grad and id(p) not in seen:
                 seen.add(id(p))
                 self.params.append(p)
-        self.buckets = []          # [flat tensor, [(param, offset, numel)], pending count, work handle]
+        self.buckets = []          # [flat tensor, [(param, offset, numel)], set of ready param ids, work handle, launched]
         self.where = {}
         self.handles = []
         if not self.active or not self.params:
@@ -150,40 +165,81 @@ class GradientAverager:
                 slots.append((p, off, p.numel()))
                 self.where[id(p)] = (gi, off)
                 off += p.numel()
-            self.buckets.append([flat, slots, len(slots), None])
+            self.buckets.append([flat, slots, set(), None, False])
         for p in self.params:
             self.handles.append(p.register_post_accumulate_grad_hook(self._hook))
 
+    # ---- arming -------------------------------------------------------------------------------------------------
+    def begin(self):
+        """Arm the hooks for the next backward of THIS model's loss."""
+        if self.armed:
+            raise RuntimeError("GradientAverager.begin(): already armed (finish() the previous backward first)")
+        self.armed = True
+        return self
+
+    def sync(self):
+        """Context manager: `with avg.sync(): loss.backward()` = begin(), backward, finish()."""
+        return _Sync(self)
+
     def _hook(self, p):
+        if not self.armed:
+            return                              # a foreign backward (or a disarmed averager): leave p.grad alone
         gi, off = self.where[id(p)]
         b = self.buckets[gi]
+        if b[4]:
+            raise RuntimeError("GradientAverager: a gradient arrived after its bucket's all-reduce was launched "
+                               "(two backward passes inside one begin()/finish())")
         view = b[0][off:off + p.numel()].view_as(p)
         if p.grad.data_ptr() != view.data_ptr():
             view.copy_(p.grad)
             p.grad = view
-        b[2] -= 1
-        if b[2] == 0:
+        b[2].add(id(p))
+        if len(b[2]) == len(b[1]):
             b[3] = _all_reduce(b[0], self.group, True)
+            b[4] = True
 
     def finish(self):
-        """Wait for every bucket, scale to the mean.  Buckets whose parameters received no gradient this backward
-        (unused parameters) are skipped on every rank alike.  Returns the number of buckets reduced."""
+        """Wait for every bucket, scale to the mean, disarm.  Buckets whose parameters received no gradient this
+        backward (unused parameters) are skipped on every rank alike.  Returns the number of buckets reduced."""
         if not self.active:
+            self.armed = False
             return 0
-        done = 0
+        done, partial = 0, False
         for b in self.buckets:
-            if b[2] == 0:
+            if b[4]:
                 if b[3] is not None:
-                    b[3].wait()
+                    b[3].wait()                 # never reuse a bucket with an all-reduce in flight
                 b[0].mul_(self.inv)
                 done += 1
-            elif b[2] != len(b[1]):
-                raise RuntimeError("GradientAverager: a bucket received gradients for only some of its parameters; "
-                                   "use average_gradients() for models with conditionally unused parameters")
-            b[2], b[3] = len(b[1]), None
+            elif b[2]:
+                partial = True
+            b[2], b[3], b[4] = set(), None, False
+        self.armed = False
+        if partial:
+            raise RuntimeError("GradientAverager: a bucket received gradients for only some of its parameters; "
+                               "use average_gradients() for models with conditionally unused parameters")
         return done
 
     def close(self):
         for h in self.handles:
             h.remove()
         self.handles = []
+
+
+class _Sync:
+    def __init__(self, avg):
+        self.avg = avg
+
+    def __enter__(self):
+        return self.avg.begin()
+
+    def __exit__(self, et, ev, tb):
+        if et is None:
+            self.avg.finish()
+        else:                       # backward raised: drop the half-filled state, do not mask the error
+            for b in self.avg.buckets:
+                if b[3] is not None:
+                    b[3].wait()
+                b[2], b[3], b[4] = set(), None, False
+            self.avg.armed = False
+        return False

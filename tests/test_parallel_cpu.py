@@ -42,6 +42,7 @@ def _worker(rank, world, port, q, overlapped=False):
             local = [p.grad.clone() for p in m.parameters()]
             avg = parallel.GradientAverager(m.parameters(), max_buckets=2)
             opt.zero_grad()                               # grads -> None, as the reference loop leaves them
+            avg.begin()
             nn.functional.mse_loss(m(xs), ys).backward()
             nb = avg.finish()
             assert all(p.grad.data_ptr() == avg.buckets[avg.where[id(p)][0]][0].data_ptr() + 4 * avg.where[id(p)][1]
@@ -103,3 +104,101 @@ def test_average_is_noop_without_process_group():
     before = [p.grad.clone() for p in m.parameters()]
     assert parallel.average_gradients(m.parameters()) == 0
     assert all(torch.equal(a, p.grad) for a, p in zip(before, m.parameters()))
+
+
+# ---- the full SRGAN iteration (P/mode.py:148-179) with one averager per model ---------------------------------------
+# d_loss.backward() reaches G's parameters (the generator output is not detached) and g_loss.backward() reaches D's:
+# every hook fires in BOTH backward passes of an iteration; only the armed averager may act.
+
+def _gan():
+    torch.manual_seed(5)
+    G = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.PReLU(), nn.Conv2d(8, 3, 3, padding=1), nn.Tanh())
+    D = nn.Sequential(nn.Conv2d(3, 8, 3, stride=2, padding=1), nn.BatchNorm2d(8), nn.LeakyReLU(), nn.Flatten(),
+                      nn.Linear(8 * 3 * 3, 1), nn.Sigmoid())
+    return G, D
+
+
+def _gan_data():
+    g = torch.Generator().manual_seed(6)
+    return torch.rand(4, 3, 6, 6, generator=g) * 2 - 1, torch.rand(4, 3, 6, 6, generator=g) * 2 - 1
+
+
+def _gan_losses(G, D, lr, gt):
+    bce, mse = nn.BCELoss(), nn.MSELoss()
+    ones, zeros = torch.ones(lr.shape[0], 1), torch.zeros(lr.shape[0], 1)
+
+    def d_loss():
+        out = G(lr)                                         # NOT detached, as in the reference
+        return bce(D(gt), ones) + bce(D(out), zeros)
+
+    def g_loss():
+        out = G(lr)
+        return 1e-3 * bce(D(out), ones) + mse(out, gt)
+    return d_loss, g_loss
+
+
+def _gan_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        G, D = _gan()
+        parallel.broadcast_parameters(G); parallel.broadcast_parameters(D)
+        lr, gt = _gan_data()
+        d_loss, g_loss = _gan_losses(G, D, lr[rank * 2:(rank + 1) * 2], gt[rank * 2:(rank + 1) * 2])
+        g_opt, d_opt = torch.optim.Adam(G.parameters(), lr=1e-3), torch.optim.Adam(D.parameters(), lr=1e-3)
+        g_avg = parallel.GradientAverager(G.parameters(), max_buckets=2)
+        d_avg = parallel.GradientAverager(D.parameters(), max_buckets=2)
+        reduced = []
+        for _ in range(2):
+            loss = d_loss()
+            g_opt.zero_grad(); d_opt.zero_grad()
+            with d_avg.sync():
+                loss.backward()
+            reduced.append(sum(1 for b in g_avg.buckets if b[4] or b[2]))      # G's hooks fired disarmed: nothing recorded
+            d_opt.step()
+            loss = g_loss()
+            g_opt.zero_grad(); d_opt.zero_grad()
+            with g_avg.sync():
+                loss.backward()
+            g_opt.step()
+        q.put((rank, reduced, [p.detach().numpy().copy() for p in list(G.parameters()) + list(D.parameters())]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_srgan_iteration_with_both_averagers():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_gan_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0][1] == [0, 0] and res[1][1] == [0, 0]
+    # single-process oracle: per step two micro-batches with separate forwards, gradients averaged, one Adam step
+    G, D = _gan()
+    lr, gt = _gan_data()
+    fns = [_gan_losses(G, D, lr[r * 2:(r + 1) * 2], gt[r * 2:(r + 1) * 2]) for r in range(2)]
+    g_opt, d_opt = torch.optim.Adam(G.parameters(), lr=1e-3), torch.optim.Adam(D.parameters(), lr=1e-3)
+
+    def averaged(model, which):
+        acc = None
+        for r in range(2):
+            G.zero_grad(); D.zero_grad()
+            fns[r][which]().backward()
+            gr = [p.grad.clone() for p in model.parameters()]
+            acc = gr if acc is None else [a + b for a, b in zip(acc, gr)]
+        G.zero_grad(); D.zero_grad()
+        for p, a in zip(model.parameters(), acc):
+            p.grad = a / 2
+    for _ in range(2):
+        averaged(D, 0); d_opt.step()
+        averaged(G, 1); g_opt.step()
+    want = [p.detach().numpy() for p in list(G.parameters()) + list(D.parameters())]
+    for w, a, b in zip(want, res[0][2], res[1][2]):
+        assert (a == b).all()
+        assert abs(w - a).max() <= 2e-6

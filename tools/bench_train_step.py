@@ -21,31 +21,13 @@ import torch
 import torch.optim as optim
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16)
-    ap.add_argument("--lr-size", type=int, default=24)
-    ap.add_argument("--host-profile", action="store_true", help="cProfile of the timed steps' enqueue path (main thread) to stderr")
-    args = ap.parse_args()
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
-    torch.cuda.set_device(local)
-    dev = torch.device(f"cuda:{local}")
-
+def build_step(dev, B=16, L=24, rank=0, overlap=True):
+    """Models, optimizers and the iteration of P/mode.py:148-179 on `dev`.  Returns (step, world-independent state dict)."""
     from bench import synthetic_state
     from srmi import losses, parallel
     from srmi.srgan_model import Discriminator, Generator
     from srmi.vgg19 import vgg19
 
-    B, L = args.batch, args.lr_size
     generator = Generator()
     generator.load_state_dict(synthetic_state(generator, 0))
     generator = generator.to(dev).train()
@@ -73,6 +55,9 @@ def main():
     fake_label = torch.zeros((B, 1), device=dev)
     parallel.broadcast_parameters(generator)
     parallel.broadcast_parameters(discriminator)
+    # gradient exchange of SURVEY 8e2: overlapped with backward (hooks armed around each model's OWN backward)
+    g_avg = parallel.GradientAverager(generator.parameters()) if overlap else None
+    d_avg = parallel.GradientAverager(discriminator.parameters()) if overlap else None
 
     def step():
         output, _ = generator(lr)
@@ -80,8 +65,12 @@ def main():
         real_prob = discriminator(gt)
         d_loss = cross_ent(real_prob, real_label) + cross_ent(fake_prob, fake_label)
         g_optim.zero_grad(); d_optim.zero_grad()
-        d_loss.backward()
-        parallel.average_gradients(discriminator.parameters())
+        if overlap:
+            with d_avg.sync():
+                d_loss.backward()
+        else:
+            d_loss.backward()
+            parallel.average_gradients(discriminator.parameters())
         d_optim.step()
         output, _ = generator(lr)
         fake_prob = discriminator(output)
@@ -89,10 +78,25 @@ def main():
         g_loss = 0.006 * _percep + 1e-3 * cross_ent(fake_prob, real_label) + \
             0.0 * tv_loss(0.006 * (hr_feat - sr_feat) ** 2) + l2_loss(output, gt)
         g_optim.zero_grad(); d_optim.zero_grad()
-        g_loss.backward()
-        parallel.average_gradients(generator.parameters())
+        if overlap:
+            with g_avg.sync():
+                g_loss.backward()
+        else:
+            g_loss.backward()
+            parallel.average_gradients(generator.parameters())
         g_optim.step()
         return d_loss, g_loss
+
+    return step
+
+
+MIN_STEP_TFLOP = 0.68      # minimal work of one iteration at B=16, LR 24 (3.4e11 MACs)
+
+
+def cfg3(steps=10, warmup=3, B=16, L=24, dev=None, dist=None, rank=0, world=1, overlap=True, host_profile=False):
+    """Time `steps` SRGAN iterations.  Returns the record dict (rank 0 prints it in main())."""
+    dev = dev or torch.device("cuda:0")
+    step = build_step(dev, B, L, rank, overlap)
 
     def barrier():
         torch.cuda.synchronize()
@@ -100,16 +104,16 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         step()
     barrier()
     prof = None
-    if args.host_profile:
+    if host_profile:
         import cProfile
         prof = cProfile.Profile()
         prof.enable()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(steps):
         d_loss, g_loss = step()
     t_host = time.perf_counter() - t0          # host time to ENQUEUE the steps (no synchronisation inside a step)
     if prof is not None:
@@ -121,15 +125,45 @@ def main():
     el = time.perf_counter() - t0
     from srmi.tiling import max_over_ranks
     el = max_over_ranks(el, dist, dev)
+    ms = el / steps * 1e3
+    rec = {"metric": "SRGAN fine-tune steps/sec (whole job)", "value": round(world * steps / el, 3),
+           "unit": "steps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+           "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(t_host / steps * 1e3, 3),
+           "hr_mp_per_s": round(world * B * (4 * L) ** 2 / 1e6 / (ms * 1e-3), 3),
+           "dtype": "f32", "data": "synthetic", "scaling": "weak",
+           "config": {"workload": f"SRGAN step P/mode.py:148-179, per GPU LR {B}x3x{L}x{L} -> HR {4*L}, "
+                                  f"D patch {4*L}, VGG19-shaped frozen stack, Adam x2",
+                      "gradient_exchange": "overlapped (GradientAverager.sync)" if overlap else "after backward"},
+           "d_loss": round(float(d_loss.detach()), 5), "g_loss": round(float(g_loss.detach()), 5)}
+    if B == 16 and L == 24:
+        tf = MIN_STEP_TFLOP / (ms * 1e-3)
+        rec["f32_equiv_tflops_minimal_work"] = round(tf, 1)
+        rec["frac_of_f32_mfma_peak"] = round(tf / 157.3, 4)
+    return rec
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16)
+    ap.add_argument("--lr-size", type=int, default=24)
+    ap.add_argument("--no-overlap", action="store_true", help="exchange gradients after backward (average_gradients)")
+    ap.add_argument("--host-profile", action="store_true", help="cProfile of the timed steps' enqueue path (main thread) to stderr")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+    torch.cuda.set_device(local)
+    dev = torch.device(f"cuda:{local}")
+    rec = cfg3(args.steps, args.warmup, args.batch, args.lr_size, dev, dist, rank, world, not args.no_overlap, args.host_profile)
     if rank == 0:
-        ms = el / args.steps * 1e3
-        print(json.dumps({"metric": "SRGAN fine-tune steps/sec (whole job)", "value": round(world * args.steps / el, 3),
-                          "unit": "steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(t_host / args.steps * 1e3, 3), "hr_mp_per_s": round(world * B * (4 * L) ** 2 / 1e6 / (ms * 1e-3), 3),
-                          "dtype": "f32", "data": "synthetic", "scaling": "weak",
-                          "config": {"workload": f"SRGAN step P/mode.py:148-179, per GPU LR {B}x3x{L}x{L} -> HR {4*L}, "
-                                                 f"D patch {4*L}, VGG19-shaped frozen stack, Adam x2"},
-                          "d_loss": round(float(d_loss), 5), "g_loss": round(float(g_loss), 5)}), flush=True)
+        print(json.dumps(rec), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

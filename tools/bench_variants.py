@@ -37,7 +37,7 @@ def run(name, model, x, out_px, flop_per_step, steps, warmup, compute, per_layer
         io = x.numel() * 4 + out_px * 4
         rec["hbm_frac_compulsory"] = round(io / el / HBM_PEAK, 4)
         rec["hbm_frac_layerwise"] = round(sum(v["algorithmic_bytes"] for v in rec["layers"].values()) / el / HBM_PEAK, 4)
-    print(json.dumps(rec), flush=True)
+    return rec
 
 
 HBM_PEAK = 8e12     # B/s, /opt/skills/guides/MI355X_MICROARCH.md
@@ -74,6 +74,54 @@ def layer_table(plan, x, reps=10):
     return out
 
 
+def cfg2(steps=10, warmup=3, compute="bf16", per_layer=True):
+    """BASELINE config 2: SRCNN on 32x1x384x384, both parameterisations (the reference's 9-3-5 128/64, SRCNN/srcnn.py:205-210,
+    and BASELINE's 9-1-5 64/32)."""
+    from srmi.keras_models import SRCNN
+    x2 = torch.rand(32, 1, 384, 384, generator=torch.Generator().manual_seed(0))
+    px2 = 32 * 384 * 384
+    return [run("cfg2 SRCNN 9-3-5 128/64 (reference), 32x1x384x384", SRCNN(), x2, px2, px2 * 171_392.0, steps, warmup,
+                compute, per_layer=per_layer),
+            run("cfg2 SRCNN 9-1-5 64/32 (BASELINE), 32x1x384x384", SRCNN(k=(9, 1, 5), ch=(64, 32)), x2, px2, px2 * 16_064.0,
+                steps, warmup, compute, per_layer=per_layer)]
+
+
+def cfg5(steps=10, warmup=3, compute="bf16", gen=None):
+    """BASELINE config 5 on ONE GPU: one 960x540 frame -> 3840x2160 through LR tiles of 270x240 + 8 px halo (8 tiles)."""
+    from srmi.srgan_model import Generator
+    from srmi.tiling import sr_tiled
+    from bench import synthetic_state
+    if gen is None:
+        gen = Generator()
+        gen.load_state_dict(synthetic_state(gen, 0))
+        gen = gen.to("cuda:0").eval().set_compute(compute)
+    frame = (torch.rand(1, 3, 540, 960, generator=torch.Generator().manual_seed(0)) * 2 - 1).to("cuda:0")
+    with torch.no_grad():
+        for _ in range(warmup):
+            sr_tiled(gen, frame, tile=(270, 240), halo=8)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            out, ntiles = sr_tiled(gen, frame, tile=(270, 240), halo=8)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / steps
+    flop = 8.2944e6 * 249_624          # useful output pixels only (halo recompute not counted)
+    return {"workload": "cfg5 SRResNet x4, 960x540 -> 3840x2160, 8 tiles of 270x240 + 8 px halo, 1 GPU",
+            "compute": compute, "ms_per_frame": round(el * 1e3, 3), "out_mp_per_s": round(8.2944 / el, 1),
+            "tflops": round(flop / el / 1e12, 1), "frac_of_bf16_peak": round(flop / el / 2.5e15, 4), "tiles": ntiles}
+
+
+def cfg4(steps=10, warmup=3, compute="bf16", blocks=23, per_layer=False):
+    """BASELINE config 4: ESRGAN-style RRDB generator (ESRGAN/untitled0.py:18-67 topology), 8x3x256x256 -> x4, bf16."""
+    from srmi.keras_models import RRDBNet
+    x4 = torch.rand(8, 3, 256, 256, generator=torch.Generator().manual_seed(0)) * 2 - 1
+    lr_px = 8 * 256 * 256
+    rec = run(f"cfg4 RRDBNet {blocks} blocks, 8x3x256x256 -> x4", RRDBNet(num_blocks=blocks), x4, lr_px * 16,
+              lr_px * 2.0 * (175_104 * blocks + 803_520), steps, warmup, compute, per_layer=per_layer)
+    rec["frac_of_bf16_peak"] = round(rec["tflops"] / 2500.0, 4)
+    return rec
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=10)
@@ -84,41 +132,13 @@ def main():
     ap.add_argument("--only", default="", help="comma list of cfg2,cfg5,cfg4 (default: all)")
     args = ap.parse_args()
     only = set(filter(None, args.only.split(",")))
-    from srmi.keras_models import SRCNN, RRDBNet
-    g = torch.Generator().manual_seed(0)
     if not only or "cfg2" in only:
-        x2 = torch.rand(32, 1, 384, 384, generator=g)
-        px2 = 32 * 384 * 384
-        run("cfg2 SRCNN 9-3-5 128/64 (reference), 32x1x384x384", SRCNN(), x2, px2, px2 * 171_392.0, args.steps,
-            args.warmup, args.compute, per_layer=True)
-        run("cfg2 SRCNN 9-1-5 64/32 (BASELINE), 32x1x384x384", SRCNN(k=(9, 1, 5), ch=(64, 32)), x2, px2, px2 * 16_064.0,
-            args.steps, args.warmup, args.compute, per_layer=True)
+        for rec in cfg2(args.steps, args.warmup, args.compute):
+            print(json.dumps(rec), flush=True)
     if not only or "cfg5" in only:
-        # cfg5: one 960x540 frame -> 3840x2160 through LR tiles of 270x240 + 8 px halo (8 tiles, here all on one GPU)
-        from srmi.srgan_model import Generator
-        from srmi.tiling import sr_tiled
-        from bench import synthetic_state
-        gen = Generator()
-        gen.load_state_dict(synthetic_state(gen, 0))
-        gen = gen.to("cuda:0").eval().set_compute(args.compute)
-        frame = (torch.rand(1, 3, 540, 960, generator=g) * 2 - 1).to("cuda:0")
-        with torch.no_grad():
-            for _ in range(args.warmup):
-                sr_tiled(gen, frame, tile=(270, 240), halo=8)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                out, ntiles = sr_tiled(gen, frame, tile=(270, 240), halo=8)
-            torch.cuda.synchronize()
-            el = (time.perf_counter() - t0) / args.steps
-        print(json.dumps({"workload": "cfg5 SRResNet x4, 960x540 -> 3840x2160, 8 tiles of 270x240 + 8 px halo, 1 GPU",
-                          "compute": args.compute, "ms_per_frame": round(el * 1e3, 3), "out_mp_per_s": round(8.2944 / el, 1),
-                          "tiles": ntiles}), flush=True)
+        print(json.dumps(cfg5(args.steps, args.warmup, args.compute)), flush=True)
     if not only or "cfg4" in only:
-        x4 = torch.rand(8, 3, 256, 256, generator=g) * 2 - 1
-        lr_px = 8 * 256 * 256
-        run(f"cfg4 RRDBNet {args.blocks} blocks, 8x3x256x256 -> x4", RRDBNet(num_blocks=args.blocks), x4, lr_px * 16,
-            lr_px * 2.0 * (175_104 * args.blocks + 803_520), args.steps, args.warmup, args.compute, per_layer=args.layers)
+        print(json.dumps(cfg4(args.steps, args.warmup, args.compute, args.blocks, args.layers)), flush=True)
 
 
 if __name__ == "__main__":
