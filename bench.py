@@ -395,8 +395,8 @@ def main():
             plan, units, kms = per_kernel_times(gen, x, reps=max(5, min(20, args.steps)))
         # dominant kernel = resblock_c64_kernel (two fused 64->64 convs; 16 launches = 59 % of the step's FLOPs and
         # ~60 % of its time); the whole 64-channel MFMA family (resblock + conv_c64) is reported beside it.
-        dom = "resblock_bf16" if args.compute == "bf16" else "generic_f32"
-        fam = ("c64_bf16", "resblock_bf16") if args.compute == "bf16" else ("generic_f32",)
+        dom = "resblock_bf16" if args.compute == "bf16" else "b3_f32"
+        fam = ("c64_bf16", "resblock_bf16") if args.compute == "bf16" else ("generic_f32", "f32t", "b3_f32", "b3h_f32")
         peak = PEAK_BF16_TFLOPS if args.compute == "bf16" else PEAK_F32_MFMA_TFLOPS
         per_layer, flops, t_dom, n_dom, f_fam, t_fam = {}, 0.0, 0.0, 0, 0.0, 0.0
         for u, (label, i, cnt) in enumerate(units):

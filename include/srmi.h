@@ -42,7 +42,10 @@ extern "C" {
 #define SRMI_NHWC 0
 #define SRMI_NCHW 1
 /* compute paths */
-#define SRMI_COMPUTE_F32 0  /* exact f32 MFMA (v_mfma_f32_32x32x2_f32): the <=1e-4 parity path */
+#define SRMI_COMPUTE_F32 0  /* f32 results: the <=1e-4 parity path.  Convs with Cin, Cout multiples of 32 run as six bf16
+                               MFMA products per k on operands split into three bf16 (an f32 FMA chain's rounding,
+                               kernels "b3_f32" / "b3h_f32"); everything else, and everything under SRMI_F32_EXACT=1,
+                               on the exact f32 MFMA v_mfma_f32_32x32x2_f32 ("f32t" / "generic_f32") */
 #define SRMI_COMPUTE_BF16 1 /* bf16 MFMA, f32 accumulate: the throughput path */
 /* activations (applied after scale/shift, before the residual add) */
 #define SRMI_ACT_NONE 0
@@ -120,8 +123,10 @@ int srmi_version(void);
 /* message for the calling thread's most recent failure ("" if none). */
 const char* srmi_last_error(void);
 
-/* name of the kernel the dispatcher selects for `d`: "generic_f32", "c64_bf16", "cin_bf16", "c64_thin_bf16",
- * "k9c3_bf16", "k9c1_bf16", "pw_bf16", "c1out_bf16". */
+/* name of the kernel that RUNS the forward conv of `d`: bf16 path "c64_bf16", "cin_bf16", "c64_thin_bf16", "k9c3_bf16",
+ * "k9c1_bf16", "pw_bf16", "c1out_bf16"; f32 path "b3h_f32" (split-bf16, 3x3 / 64 input channels, halo tile in LDS),
+ * "b3_f32" (split-bf16, general), "f32t" (exact f32 MFMA, LDS-tiled), "generic_f32" (exact f32 MFMA, no LDS: NCHW or
+ * bf16-storage inputs, odd shapes).  The packed-weight FORMAT is a property of this name (see below). */
 int srmi_conv2d_kernel_name(const srmi_conv_desc* d, char* buf, size_t buf_len);
 
 /* The HBM-bound SRCNN layers (SRCNN/srcnn.py:205-210) by name: the same descriptors go through srmi_conv2d_fwd, these
@@ -136,11 +141,19 @@ int srmi_srcnn_layer_c1in(const srmi_conv_args* a, void* stream);
 int srmi_srcnn_layer_c1out(const srmi_conv_args* a, void* stream);
 
 /* bytes of the kernel-native packed weight buffer for `d`.  The format (and size) belongs to the kernel the dispatcher
- * selects for `d`: for SRMI_COMPUTE_F32 with NHWC f32 input, Cin and Cout multiples of 32 and <= 25 taps it is the
- * split-bf16 operand of csrc/conv_b3_f32.hip (three bf16 planes, 6 B per weight; f32 products rebuilt from six bf16
- * products per k), otherwise [tap][Cin][Cout] f32.  The choice depends on the weight's shape, layouts and dtypes only,
- * never on N / H / W, so one packed buffer serves every input size.  Environment SRMI_F32_EXACT=1 (read once, at the
- * first call) keeps every f32 conv on the exact-f32 MFMA kernel and its format. */
+ * selects for `d` (srmi_conv2d_kernel_name).  PACK WITH THE DESCRIPTOR YOU LAUNCH WITH: a packed buffer may be shared by
+ * two descriptors only if srmi_conv2d_kernel_name returns the same name for both and their Cin, Cout, kh, kw agree.
+ * The name never depends on N / H / W (one packed buffer serves every input size), but it does depend on more than
+ * the weight's shape:
+ *   "b3_f32"   SRMI_COMPUTE_F32, NHWC f32 input, Cin and Cout multiples of 32, <= 25 taps, kh*kw*Cin >= 256:
+ *              [plane][tap][n][k] bf16, three planes (6 B per weight);
+ *   "b3h_f32"  the same AND 3x3, stride 1, pad 1, Cin == 64, Cout % 64 == 0, act == SRMI_ACT_NONE, shuffle == 1,
+ *              NHWC f32 output and f32 residual: [plane][tap][nt][ks][lane][8] bf16 - the SAME byte count as "b3_f32"
+ *              in a different order, so e.g. an act = NONE and an act = RELU descriptor of one 64 -> 64 3x3 weight need
+ *              two packed buffers (a mismatch is not detectable from the size);
+ *   "f32t" / "generic_f32"  [tap][Cin_pad][Cout_pad] f32.
+ * Environment SRMI_F32_EXACT=1 (read once, at the first call) keeps every f32 conv on the exact-f32 MFMA kernels and
+ * their format. */
 int srmi_conv2d_packed_weight_bytes(const srmi_conv_desc* d, size_t* bytes);
 
 /* OIHW f32 (the `nn.Conv2d.weight` layout, P/ops.py:11) -> kernel-native packed layout; runs on

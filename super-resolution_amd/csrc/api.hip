@@ -208,7 +208,8 @@ int srmi_conv2d_kernel_name(const srmi_conv_desc* d, char* buf, size_t buf_len) 
     ConvGeom g;
     int rc = conv_geom(*d, &g);
     if (rc) return rc;
-    snprintf(buf, buf_len, "%s", kernel_label(select_kernel(*d)));
+    const int k = select_kernel(*d);
+    snprintf(buf, buf_len, "%s", k == K_GENERIC_F32 ? generic_kernel_label(*d, g) : kernel_label(k));
     return SRMI_OK;
 }
 

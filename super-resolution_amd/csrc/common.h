@@ -94,6 +94,7 @@ size_t generic_packed_bytes(const srmi_conv_desc& d);
 int generic_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s);
 int generic_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s, void* ws = nullptr, size_t ws_bytes = 0);
 size_t generic_workspace_bytes(const srmi_conv_desc& d, const ConvGeom& g);
+const char* generic_kernel_label(const srmi_conv_desc& d, const ConvGeom& g);   // which f32 kernel runs d: b3h_f32 | b3_f32 | f32t | generic_f32
 
 // bf16 MFMA kernel for 3x3 / Cin=64 / Cout%64==0 (conv_c64_bf16.hip)
 bool c64_supported(const srmi_conv_desc& d);

@@ -412,6 +412,18 @@ static void generic_fill(GenericParams& p, const srmi_conv_args& a, const ConvGe
     p.b3 = b3h_fwd_ok(d) ? 2 : b3_fwd_ok(d) ? 1 : 0;
 }
 
+// The f32 kernel generic_run picks for the forward conv of `d` (16-byte aligned buffers assumed, as every caller's are).
+const char* generic_kernel_label(const srmi_conv_desc& d, const ConvGeom& g) {
+    srmi_conv_args a;
+    memset(&a, 0, sizeof(a));
+    a.d = d;
+    GenericParams p;
+    generic_fill(p, a, g);
+    if (p.b3 == 2) return "b3h_f32";
+    if (p.b3) return "b3_f32";
+    return f32t_supported(p) ? "f32t" : "generic_f32";
+}
+
 static int generic_run(const GenericParams& p0) {
     GenericParams p = p0;
     hipStream_t s = p.stream;

@@ -50,14 +50,20 @@ def test_kernel_selection():
     d = Fn.make_desc(16, 96, 96, 64, 256, 3, in_dtype=L.BF16, out_dtype=L.BF16, compute=L.COMPUTE_BF16, shuffle=2)
     assert L.kernel_name(d) == "c64_bf16"
     d = Fn.make_desc(16, 96, 96, 64, 64, 3)                      # f32 compute -> f32 path
-    assert L.kernel_name(d) == "generic_f32"
     # Cin, Cout multiples of 32: three bf16 planes of the split-operand kernel; [tap][Cin][Cout] f32 with SRMI_F32_EXACT=1
     exact = os.environ.get("SRMI_F32_EXACT", "0") not in ("", "0")
+    # the name is the kernel that RUNS: 3x3 / 64 channels / no activation -> the halo-tile split kernel, with an
+    # activation the general split kernel (a different operand order in the same byte count: srmi.h)
+    assert L.kernel_name(d) == ("f32t" if exact else "b3h_f32")
+    d_relu = Fn.make_desc(16, 96, 96, 64, 64, 3, act=L.ACT_RELU)
+    assert L.kernel_name(d_relu) == ("f32t" if exact else "b3_f32")
+    assert L.kernel_name(Fn.make_desc(1, 8, 8, 3, 64, 9, in_layout=L.NCHW)) == "generic_f32"    # NCHW input: no LDS-tiled kernel
+    assert L.kernel_name(Fn.make_desc(2, 8, 8, 64, 3, 3)) == "f32t"                             # Cout % 32 != 0: exact f32 MFMA
     assert L.packed_weight_bytes(d) == (9 * 64 * 64 * 4 if exact else 3 * 9 * 64 * 64 * 2)
     d = Fn.make_desc(1, 8, 8, 3, 64, 9)                          # Cin padded to 8, Cout to 64
     assert L.packed_weight_bytes(d) == 81 * 8 * 64 * 4
     d = Fn.make_desc(2, 8, 8, 64, 64, 3, stride=2, in_dtype=L.BF16, out_dtype=L.BF16, compute=L.COMPUTE_BF16)
-    assert L.kernel_name(d) == "generic_f32"                    # stride 2 is not a c64 shape
+    assert L.kernel_name(d) == "generic_f32"                    # stride 2 is not a c64 shape; bf16 storage -> the no-LDS kernel
 
 
 @pytest.mark.parametrize("field,value", [("Cin", 0), ("Cout", -1), ("stride", 0), ("kh", 0), ("in_dtype", 7),

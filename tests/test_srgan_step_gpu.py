@@ -216,6 +216,33 @@ def test_srgan_finetune_step(golden_dir, fname):
             _cmp(g, "after_d", name, v, 2e-4, 1e-6)
         elif name.endswith("num_batches_tracked"):
             assert int(v) == int(g["after_d:" + name]) == 3
+    # post-step PARAMETERS (the fixture's after_g / after_d entries are the reference's weights after its
+    # own Adam steps).  Adam's first step moves an element by lr * g / (|g| + eps): at most lr, and by the same amount
+    # in both implementations wherever the gradient's sign is not in doubt.  Every element must be within 2 lr of the
+    # reference's; elements whose reference gradient stands clear of the family's allowed gradient error ("solid":
+    # |g| > 4 x the max-abs gate) must agree to lr * eps / |g| + 2e-6 - a wrong Adam formula, a stale or mis-scaled
+    # gradient, or an update applied twice / not at all would fail this by orders of magnitude.
+    LR_ADAM, EPS_ADAM = 1e-4, 1e-8
+    checked = {"after_g": 0, "after_d": 0}
+    for prefix, gprefix, module, keys, tol in (("after_g", "ggrad", generator, gkeys, gtol),
+                                               ("after_d", "dgrad", discriminator, dkeys, dtol)):
+        for name, p_ in module.named_parameters():
+            ref, mine = _fixture_tensor(g, prefix, name, p_)
+            assert ref is not None, (prefix, name)
+            d = (mine.double() - ref.double()).abs()
+            assert float(d.max()) <= 2 * LR_ADAM + 1e-7, (prefix, name, float(d.max()))
+            if _bn_fed_bias(name, keys):
+                continue
+            gref, _ = _fixture_tensor(g, gprefix, name)
+            if gref is None or gref.numel() != ref.numel():
+                continue
+            ga = gref.double().abs()
+            solid = ga > 4.0 * tol[0] * float(ga.max())
+            if solid.any():
+                bound = LR_ADAM * EPS_ADAM / ga[solid] + 2e-6
+                assert bool((d[solid] <= bound).all()), (prefix, name, float((d[solid] - bound).max()))
+                checked[prefix] += int(solid.sum())
+    assert checked["after_g"] > 100 and checked["after_d"] > 100, checked          # (fewer elements stand clear of a wide gate)
 
 
 def test_srgan_step_is_bit_reproducible(golden_dir):
