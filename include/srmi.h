@@ -27,7 +27,8 @@
 extern "C" {
 #endif
 
-#define SRMI_VERSION 113 /* 0.1.3: fused generator tail (srmi_conv2d_fwd_pair), SRCNN kernels, persistent chain removed */
+#define SRMI_VERSION 114 /* 0.1.4: bn_train_stats counts num_batches_tracked, epilogue_bwd zero-fills the BN-fed bias gradient;
+                            srmi_conv2d_kernel_name reports the f32 kernel that runs */
 
 /* error codes */
 #define SRMI_OK 0
@@ -324,7 +325,9 @@ int srmi_train_workspace_bytes(int32_t C, size_t* bytes);
  * running_mean / running_var are non-NULL they are updated in place as nn.BatchNorm2d does
  * (r = (1-momentum) r + momentum * stat, unbiased variance).  P/ops.py:24-26. */
 int srmi_bn_train_stats(const float* z, int64_t M, int32_t C, float eps, float momentum, float* mean, float* rstd,
-                        float* running_mean, float* running_var, void* ws, void* stream);
+                        float* running_mean, float* running_var, int64_t* num_batches_tracked, void* ws, void* stream);
+/* (num_batches_tracked, may be NULL: the module's int64 counter, incremented by 1 on the device by the same launch that
+ *  updates the running statistics - nn.BatchNorm2d's `self.num_batches_tracked.add_(1)`.) */
 
 /* y = store(act(bn(z))) + residual.  mean/rstd/gamma/beta are read only when d->bn; residual (shaped like y)
  * may be NULL.  Replaces BatchNorm2d + activation + PixelShuffle + `res += x` (P/ops.py:24-29, :47, :75-83). */
@@ -340,7 +343,9 @@ int srmi_epilogue_fwd(const srmi_epi_desc* d, const float* z, const float* mean,
  * The residual's gradient is dy itself.  autograd of the same modules in the reference (P/mode.py:105, :160, :178). */
 int srmi_epilogue_bwd(const srmi_epi_desc* d, const float* z, const float* dy, const float* mean, const float* rstd,
                       const float* gamma, const float* beta, const float* alpha, float* dz, float* dsum1,
-                      float* dsum2, float* dalpha, void* ws, void* stream);
+                      float* dsum2, float* dalpha, float* dzero, void* ws, void* stream);
+/* (dzero, may be NULL: [C] floats set to 0 by the finalize launch - the gradient of a conv bias that feeds train-mode
+ *  BatchNorm, which removes the mean: exactly zero.) */
 
 /* Input gradient of the conv described by `d` (geometry fields only; NHWC f32): dx[N,H,W,Cin] from
  * dz[N,Ho,Wo,Cout].  The weights are packed once per parameter version by srmi_conv2d_dgrad_pack_weights.

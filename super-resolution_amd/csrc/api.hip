@@ -57,12 +57,12 @@ int y_metrics(const float* sr, const float* gt, int nimg, int H, int W, int gt_H
 
 size_t train_workspace_bytes(int C);
 int bn_train_stats(const float* z, long long M, int C, float eps, float momentum, float* mean, float* rstd,
-                   float* rmean, float* rvar, void* ws, hipStream_t s);
+                   float* rmean, float* rvar, long long* nbt, void* ws, hipStream_t s);
 int epilogue_fwd(const srmi_epi_desc& d, const float* z, const float* mean, const float* rstd, const float* gamma,
                  const float* beta, const float* alpha, const float* residual, float* y, hipStream_t s);
 int epilogue_bwd(const srmi_epi_desc& d, const float* z, const float* dy, const float* mean, const float* rstd,
                  const float* gamma, const float* beta, const float* alpha, float* dz, float* dsum1, float* dsum2,
-                 float* dalpha, void* ws, hipStream_t s);
+                 float* dalpha, float* dzero, void* ws, hipStream_t s);
 int maxpool_fwd(const float* x, float* y, int N, int H, int W, int C, hipStream_t s);
 int maxpool_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, hipStream_t s);
 int mse_bwd(const float* a, const float* b, const float* gout, size_t n, float* da, float* db, hipStream_t s);
@@ -495,12 +495,13 @@ int srmi_train_workspace_bytes(int32_t C, size_t* bytes) {
 }
 
 int srmi_bn_train_stats(const float* z, int64_t M, int32_t C, float eps, float momentum, float* mean, float* rstd,
-                        float* running_mean, float* running_var, void* ws, void* stream) {
+                        float* running_mean, float* running_var, int64_t* num_batches_tracked, void* ws, void* stream) {
     if (!z || !mean || !rstd || !ws || M <= 0 || C <= 0 || (uintptr_t)ws % 8) {
         set_error("bn_train_stats: bad arguments (M=%lld C=%d)", (long long)M, C);
         return SRMI_EINVAL;
     }
-    return bn_train_stats(z, M, C, eps, momentum, mean, rstd, running_mean, running_var, ws, (hipStream_t)stream);
+    return bn_train_stats(z, M, C, eps, momentum, mean, rstd, running_mean, running_var, (long long*)num_batches_tracked, ws,
+                          (hipStream_t)stream);
 }
 
 int srmi_epilogue_fwd(const srmi_epi_desc* d, const float* z, const float* mean, const float* rstd,
@@ -517,7 +518,7 @@ int srmi_epilogue_fwd(const srmi_epi_desc* d, const float* z, const float* mean,
 
 int srmi_epilogue_bwd(const srmi_epi_desc* d, const float* z, const float* dy, const float* mean, const float* rstd,
                       const float* gamma, const float* beta, const float* alpha, float* dz, float* dsum1,
-                      float* dsum2, float* dalpha, void* ws, void* stream) {
+                      float* dsum2, float* dalpha, float* dzero, void* ws, void* stream) {
     int rc = epi_check("epilogue_bwd", d);
     if (rc) return rc;
     if (!z || !dy || !dz || !ws || (uintptr_t)ws % 8 || (d->bn && (!mean || !rstd || !gamma || !beta)) ||
@@ -525,7 +526,7 @@ int srmi_epilogue_bwd(const srmi_epi_desc* d, const float* z, const float* dy, c
         set_error("epilogue_bwd: NULL or misaligned argument");
         return SRMI_EINVAL;
     }
-    return epilogue_bwd(*d, z, dy, mean, rstd, gamma, beta, alpha, dz, dsum1, dsum2, dalpha, ws, (hipStream_t)stream);
+    return epilogue_bwd(*d, z, dy, mean, rstd, gamma, beta, alpha, dz, dsum1, dsum2, dalpha, dzero, ws, (hipStream_t)stream);
 }
 
 static int grad_geom(const char* what, const srmi_conv_desc* d, ConvGeom* g) {

@@ -49,6 +49,33 @@ constexpr int UF_TAP_BYTES = 8192;
 constexpr float UF_FIX = 262144.f;         // 2^18 fixed-point units per 1.0
 constexpr float UF_CLAMP = 900.f;          // |partial| clamp: 9 taps x 900 x 2^18 < 2^31 (a sane net is 100x below)
 
+// Row m (0..31) of the last conv's scatter GEMM -> 3 * tap + oc (0..26), or -1 for a zero row.
+// The accumulation image is PLANAR ([oc][OH][UF_PITCH] ints) and the rows are dealt to the MFMA row groups q so that the LDS
+// adds of one instruction do not collide (ds_add_u32: two groups of 32 lanes = two q's x 16 neighbouring T pixels, 32 banks):
+// a lane's address is pixel base + row offset; neighbouring T pixels are 2 ints apart, so 16 lanes of one q cover the 16
+// banks of ONE parity; rows whose (dy + dx) is even sit in q = 0 / 2 and rows whose (dy + dx) is odd in q = 1 / 3, and
+// with an ODD pitch and an EVEN plane size the two q's of a group then always differ in parity.  The pitch 57 makes
+// the wrap of a flattened pixel tile to the next region row a multiple of 32 banks (2 * 57 - 2 * 25 = 64), so wrapped
+// tiles stay collision-free too.  Model (tools/lds_conflict_sim.py conventions): 0 conflict cycles per workgroup; the
+// round-2 layout ([y][x][3] interleaved, rows in tap order): 3120, measured 11.9 K.
+__host__ __device__ constexpr int uf_row(int m) {
+    const int mt = m >> 4, q = (m >> 2) & 3, e = m & 3;
+    const int slot = (q >> 1) * 8 + mt * 4 + e;      // position inside the parity class of q
+    int cnt = 0;
+    for (int dy = 0; dy < 3; ++dy)
+        for (int dx = 0; dx < 3; ++dx)
+            for (int oc = 0; oc < 3; ++oc)
+                if (((dy + dx) & 1) == (q & 1)) {
+                    if (cnt == slot) return (dy * 3 + dx) * 3 + oc;
+                    ++cnt;
+                }
+    return -1;
+}
+struct UfRowTable { int v[32]; };
+constexpr UfRowTable uf_row_table() { UfRowTable t{}; for (int m = 0; m < 32; ++m) t.v[m] = uf_row(m); return t; }
+__device__ constexpr UfRowTable UF_ROWS = uf_row_table();
+constexpr int UF_PITCH_EXTRA = 5;          // OW + 5 = 57 for the 24 x 24 tile
+
 template <int TH, int TW, int NW, int PT, int SLOTS>
 __global__ __launch_bounds__(NW * 64, 1) void upfuse_kernel(UpFuseParams p) {
     constexpr int NTH = NW * 64;
@@ -59,7 +86,10 @@ __global__ __launch_bounds__(NW * 64, 1) void upfuse_kernel(UpFuseParams p) {
     constexpr int ROWP = XC;                           // LDS row pitch in pixels (the swizzle key depends on the column only)
     constexpr int IN_BYTES = XR * ROWP * 128;
     constexpr int OH = 2 * TH + 4, OW = 2 * TW + 4;    // accumulation image with a 2-pixel apron: no bounds checks on the adds
-    constexpr int OB_BYTES = OH * OW * 3 * 4;
+    constexpr int OP = OW + UF_PITCH_EXTRA;            // row pitch of a plane (ints): odd, 2 * OP - 2 * RC a multiple of 32
+    constexpr int PL = OH * OP;                        // plane size (ints): even
+    static_assert(OP % 2 == 1 && PL % 2 == 0 && (2 * OP - 2 * (TW + 1)) % 32 == 0, "collision-free layout of the scatter adds");
+    constexpr int OB_BYTES = 3 * PL * 4;
     constexpr int WAVE_BYTES = UF_TAP_BYTES / NW;
     static_assert(WAVE_BYTES == 1024, "one LDS-DMA instruction per wave and tap");
     constexpr int NCHUNK = 4;
@@ -111,26 +141,27 @@ __global__ __launch_bounds__(NW * 64, 1) void upfuse_kernel(UpFuseParams p) {
     bf16x8 w7f[2][2];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
-        const int m = 16 * mt + pl;
-        const int tap = m / 3, oc = m - 3 * tap;
+        const int r = UF_ROWS.v[16 * mt + pl];          // A-fragment row m = 16 mt + pl (see uf_row)
+        const int tap = r / 3, oc = r - 3 * tap;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             u32x4 v = {0u, 0u, 0u, 0u};
-            if (m < 27) v = *(const u32x4*)((const unsigned char*)p.w7 + ((size_t)((tap * 2 + ks) * 64 + q * 16 + oc)) * 16);
+            if (r >= 0) v = *(const u32x4*)((const unsigned char*)p.w7 + ((size_t)((tap * 2 + ks) * 64 + q * 16 + oc)) * 16);
             w7f[mt][ks] = __builtin_bit_cast(bf16x8, v);
         }
     }
     // where this lane's 8 results (rows 16 mt + 4 q + e) go, relative to its T pixel, in ints of the accumulation image:
-    // tap (dy, dx) of T pixel (Y, X) belongs to output (Y - dy + 1, X - dx + 1), channel oc.  Rows >= 27 carry zeros.
+    // tap (dy, dx) of T pixel (Y, X) belongs to output (Y - dy + 1, X - dx + 1), plane oc.  Zero rows add 0 to the
+    // lane's own pixel (+ 1 for the odd class: keeps the instruction's parity split).
     int ooff[2][4];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int m = 16 * mt + 4 * q + e;
-            const int tap = m / 3, oc = m - 3 * tap;
+            const int r = UF_ROWS.v[16 * mt + 4 * q + e];
+            const int tap = r / 3, oc = r - 3 * tap;
             const int dy = tap / 3, dx = tap - 3 * dy;
-            ooff[mt][e] = m < 27 ? ((1 - dy) * OW + (1 - dx)) * 3 + oc : 0;
+            ooff[mt][e] = r >= 0 ? oc * PL + (1 - dy) * OP + (1 - dx) : (q & 1);
         }
 
     // ---- stage the input halo tile (global NHWC bf16 -> registers -> swizzled LDS), zero the accumulation image ----
@@ -178,7 +209,7 @@ __global__ __launch_bounds__(NW * 64, 1) void upfuse_kernel(UpFuseParams p) {
             const int gy = y0 + ti - (sq >> 1), gx = x0 + tj - (sq & 1);
             live |= (flat < RH * RC && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) ? 1u << (8 * sq + k) : 0u;
         }
-        obase[k] = ((2 * ti + 2) * OW + (2 * tj + 2)) * 3;
+        obase[k] = (2 * ti + 2) * OP + (2 * tj + 2);
         brow[k] = ti * (ROWP * 128);
         bcol[k] = tj;
     }
@@ -262,7 +293,7 @@ __global__ __launch_bounds__(NW * 64, 1) void upfuse_kernel(UpFuseParams p) {
                     sl[4 * hi + 2 * v4 + e] = (f32x2){csl[2 * e], csl[2 * e + 1]};
                 }
             }
-        const int sub = -(si * OW + sj) * 3;
+        const int sub = -(si * OP + sj);
         const unsigned live_s = live >> (8 * s);
         auto tail = [&](auto KIND) {
 #pragma unroll
@@ -294,7 +325,7 @@ __global__ __launch_bounds__(NW * 64, 1) void upfuse_kernel(UpFuseParams p) {
                     const float f0 = __builtin_amdgcn_fmed3f(d0[e], -UF_CLAMP, UF_CLAMP) * UF_FIX;
                     const float f1 = __builtin_amdgcn_fmed3f(d1[e], -UF_CLAMP, UF_CLAMP) * UF_FIX;
                     atomicAdd(dst + ooff[0][e], (int)__builtin_rintf(f0));
-                    atomicAdd(dst + ooff[1][e], (int)__builtin_rintf(f1));     // (rows 27..31: zero weights, adds 0 to the lane's own pixel)
+                    atomicAdd(dst + ooff[1][e], (int)__builtin_rintf(f1));     // (zero rows: zero weights, add 0)
                 }
             }
         };
@@ -320,11 +351,11 @@ __global__ __launch_bounds__(NW * 64, 1) void upfuse_kernel(UpFuseParams p) {
         if (Y >= Hout || X >= Wout) continue;
         const float sc = oc == 0 ? s7[0] : oc == 1 ? s7[1] : s7[2];
         const float sh = oc == 0 ? h7[0] : oc == 1 ? h7[1] : h7[2];
-        const int* src = obuf + ((Yo + 2) * OW + 4 * cq + 2) * 3 + oc;
+        const int* src = obuf + oc * PL + (Yo + 2) * OP + 4 * cq + 2;
         f32x4 v;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const float z = (float)src[3 * e] * sc + sh;
+            const float z = (float)src[e] * sc + sh;
             if (p.act7 == SRMI_ACT_TANH) {
                 // tanh z = sign(z) (1 - t) / (1 + t), t = exp(-2 |z|): hardware exp2 and rcp (1 ulp each), |error| < 3e-7
                 const float t = __builtin_amdgcn_exp2f(-2.885390082f * __builtin_fabsf(z));

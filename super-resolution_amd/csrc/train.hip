@@ -136,8 +136,9 @@ __device__ __forceinline__ void slot_sums(const double* __restrict__ acc, int ns
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ acc, int nslots, long long M, int C,
                                                           float eps, float momentum, float* __restrict__ mean,
                                                           float* __restrict__ rstd, float* __restrict__ rmean,
-                                                          float* __restrict__ rvar) {
+                                                          float* __restrict__ rvar, long long* __restrict__ nbt) {
     __shared__ double sh[2][FIN_G][FIN_CH];
+    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;       // nn.BatchNorm2d: num_batches_tracked.add_(1)
     const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH, g = threadIdx.x / FIN_CH;
     double t[2];
     slot_sums<2>(acc, nslots, C, c, g, t, sh);
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(CH_BLOCK) void bn_bwd_apply_kernel(EpiParams p) {
 __global__ __launch_bounds__(256) void epilogue_bwd_finalize_kernel(double* __restrict__ acc, int nslots, int C,
                                                                     int n_alpha, int bn, int Cf, int rr, int dcr,
                                                                     float* __restrict__ dsum1, float* __restrict__ dsum2,
-                                                                    float* __restrict__ dalpha) {
+                                                                    float* __restrict__ dalpha, float* __restrict__ dzero) {
     __shared__ double sh3[3][FIN_G][FIN_CH];
     __shared__ double sh[256];
     double* tot = acc + (size_t)nslots * 3 * C;
@@ -354,6 +355,7 @@ __global__ __launch_bounds__(256) void epilogue_bwd_finalize_kernel(double* __re
         tot[c] = t[0]; tot[C + c] = t[1]; tot[2 * C + c] = t[2];        // [2]: dalpha terms per conv channel
         if (dsum1) dsum1[c] = (float)t[0];
         if (bn && dsum2) dsum2[c] = (float)t[1];
+        if (dzero) dzero[c] = 0.f;
         return;
     }
     if (!dalpha || n_alpha <= 0) return;
@@ -529,7 +531,7 @@ static bool lane_keeps_channels(int C) { return C % 4 == 0 && C >= 4 && 256 % (C
 size_t train_workspace_bytes(int C) { return ((size_t)max_slots(C) * 3 + 3) * C * sizeof(double); }
 
 int bn_train_stats(const float* z, long long M, int C, float eps, float momentum, float* mean, float* rstd,
-                   float* rmean, float* rvar, void* ws, hipStream_t s) {
+                   float* rmean, float* rvar, long long* nbt, void* ws, hipStream_t s) {
     const dim3 grid = ch_grid(M, C);      // every slot of the grid is written: nothing to clear
     if (C % 4 == 0 && vec4_ptrs({z}))
         hipLaunchKernelGGL(bn_stats_v4_kernel, grid, dim3(CH_BLOCK), 0, s, z, M, C, (double*)ws);
@@ -538,7 +540,7 @@ int bn_train_stats(const float* z, long long M, int C, float eps, float momentum
     int rc = hip_check(hipGetLastError(), "bn_stats_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, (const double*)ws, (int)grid.x, M, C,
-                       eps, momentum, mean, rstd, rmean, rvar);
+                       eps, momentum, mean, rstd, rmean, rvar, nbt);
     return hip_check(hipGetLastError(), "bn_finalize_kernel");
 }
 
@@ -567,7 +569,7 @@ int epilogue_fwd(const srmi_epi_desc& d, const float* z, const float* mean, cons
 
 int epilogue_bwd(const srmi_epi_desc& d, const float* z, const float* dy, const float* mean, const float* rstd,
                  const float* gamma, const float* beta, const float* alpha, float* dz, float* dsum1, float* dsum2,
-                 float* dalpha, void* ws, hipStream_t s) {
+                 float* dalpha, float* dzero, void* ws, hipStream_t s) {
     EpiParams p = epi_params(d);
     p.z = z; p.dy = dy; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.alpha = alpha;
     p.dz = dz; p.acc = (double*)ws;
@@ -585,7 +587,7 @@ int epilogue_bwd(const srmi_epi_desc& d, const float* z, const float* dy, const 
     }
     // totals + parameter gradients (zero slots: all sums are zero)
     hipLaunchKernelGGL(epilogue_bwd_finalize_kernel, dim3((d.C + FIN_CH - 1) / FIN_CH + 1), dim3(256), 0, s, (double*)ws, p.nslots,
-                       d.C, n_alpha, d.bn, p.Cf, d.shuffle * d.shuffle, p.dcr, dsum1, dsum2, dalpha);
+                       d.C, n_alpha, d.bn, p.Cf, d.shuffle * d.shuffle, p.dcr, dsum1, dsum2, dalpha, dzero);
     rc = hip_check(hipGetLastError(), "epilogue_bwd_finalize_kernel");
     if (rc) return rc;
     if (p.M > 0 && d.bn) {

@@ -226,11 +226,10 @@ class FusedConvFn(torch.autograd.Function):
             track = bn.track_running_stats and bn.running_mean is not None
             if bn.momentum is None:
                 raise NotImplementedError("srmi: BatchNorm2d(momentum=None) (cumulative average) is not supported")
+            nbt = bn.num_batches_tracked if track else None      # counted on the device by the finalize launch
             L.check(lib.srmi_bn_train_stats(z.data_ptr(), M, Cout, float(bn.eps), float(bn.momentum), mean.data_ptr(),
                                             rstd.data_ptr(), _ptr(bn.running_mean) if track else None,
-                                            _ptr(bn.running_var) if track else None, ws.data_ptr(), st))
-            if track and bn.num_batches_tracked is not None:
-                bn.num_batches_tracked.add_(1)
+                                            _ptr(bn.running_var) if track else None, _ptr(nbt), ws.data_ptr(), st))
         r = cfg.shuffle
         ed = L.EpiDesc(N, Ho, Wo, Cout, cfg.act, cfg.act_param, cfg.apc, r, cfg.order, int(bn is not None))
         y = _empty_cl((N, Cout // (r * r), Ho * r, Wo * r), dev)
@@ -263,9 +262,12 @@ class FusedConvFn(torch.autograd.Function):
         dsum1 = torch.empty(Cout, dtype=torch.float32, device=dev)
         dsum2 = torch.empty(Cout, dtype=torch.float32, device=dev) if cfg.bn is not None else None
         dalpha = torch.empty_like(alpha) if alpha is not None else None
+        # the bias of a conv feeding train-mode BN has an exactly-zero gradient (BN removes the mean): zero-filled by the
+        # finalize launch of the epilogue backward, not by a fill launch of its own
+        dzero = torch.empty(Cout, dtype=torch.float32, device=dev) if (cfg.bn is not None and ctx.has_bias) else None
         L.check(lib.srmi_epilogue_bwd(C.byref(ed), z.data_ptr(), dy.data_ptr(), _ptr(mean), _ptr(rstd), _ptr(gamma),
                                       _ptr(beta), _ptr(alpha), dz.data_ptr(), dsum1.data_ptr(), _ptr(dsum2),
-                                      _ptr(dalpha), ws.data_ptr(), st))
+                                      _ptr(dalpha), _ptr(dzero), ws.data_ptr(), st))
         need = ctx.needs_input_grad
         dx = dw = dbias = dgamma = dbeta = None
         if need[1]:
@@ -285,8 +287,7 @@ class FusedConvFn(torch.autograd.Function):
                                           plan.ws_dgrad, st))
         if cfg.bn is not None:
             dgamma, dbeta = dsum2, dsum1
-            # the bias of a conv feeding train-mode BN has an exactly-zero gradient (BN removes the mean)
-            dbias = torch.zeros(Cout, dtype=torch.float32, device=dev) if ctx.has_bias else None
+            dbias = dzero
         else:
             dbias = dsum1 if ctx.has_bias else None
         return dx, dw, dbias, dgamma, dbeta, dalpha if need[5] else None, dy if ctx.has_res else None, None

@@ -9,6 +9,7 @@ SURVEY 8e2 run over RCCL (srmi.parallel.average_gradients).
 Prints one JSON line: steps/s (whole job), ms per step, HR megapixels/s.  Not the headline metric (bench.py is).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -21,7 +22,7 @@ import torch
 import torch.optim as optim
 
 
-def build_step(dev, B=16, L=24, rank=0, overlap=True):
+def build_step(dev, B=16, L=24, rank=0, overlap=True, literal=False):
     """Models, optimizers and the iteration of P/mode.py:148-179 on `dev`.  Returns (step, world-independent state dict)."""
     from bench import synthetic_state
     from srmi import losses, parallel
@@ -59,9 +60,15 @@ def build_step(dev, B=16, L=24, rank=0, overlap=True):
     g_avg = parallel.GradientAverager(generator.parameters()) if overlap else None
     d_avg = parallel.GradientAverager(discriminator.parameters()) if overlap else None
 
+    from srmi.mode import _no_param_grads
+
+    # The iteration as srmi.mode.train runs it (tests/test_mode_train_gpu.py: bit-equal to the reference's loop body in
+    # every parameter, buffer and loss): the generator output is detached for the D step and D's parameters collect no
+    # gradients in the G step - the reference computes both and throws them away (P/mode.py:149-160, :165-178; SURVEY 3.3
+    # "minimal necessary work").  `literal=True` keeps the wasted work.
     def step():
         output, _ = generator(lr)
-        fake_prob = discriminator(output)
+        fake_prob = discriminator(output if literal else output.detach())
         real_prob = discriminator(gt)
         d_loss = cross_ent(real_prob, real_label) + cross_ent(fake_prob, fake_label)
         g_optim.zero_grad(); d_optim.zero_grad()
@@ -73,17 +80,18 @@ def build_step(dev, B=16, L=24, rank=0, overlap=True):
             parallel.average_gradients(discriminator.parameters())
         d_optim.step()
         output, _ = generator(lr)
-        fake_prob = discriminator(output)
-        _percep, hr_feat, sr_feat = VGG_loss((gt + 1.0) / 2.0, (output + 1.0) / 2.0, layer="relu5_4")
-        g_loss = 0.006 * _percep + 1e-3 * cross_ent(fake_prob, real_label) + \
-            0.0 * tv_loss(0.006 * (hr_feat - sr_feat) ** 2) + l2_loss(output, gt)
-        g_optim.zero_grad(); d_optim.zero_grad()
-        if overlap:
-            with g_avg.sync():
+        with (contextlib.nullcontext() if literal else _no_param_grads(discriminator)):
+            fake_prob = discriminator(output)
+            _percep, hr_feat, sr_feat = VGG_loss((gt + 1.0) / 2.0, (output + 1.0) / 2.0, layer="relu5_4")
+            g_loss = 0.006 * _percep + 1e-3 * cross_ent(fake_prob, real_label) + \
+                0.0 * tv_loss(0.006 * (hr_feat - sr_feat) ** 2) + l2_loss(output, gt)
+            g_optim.zero_grad(); d_optim.zero_grad()
+            if overlap:
+                with g_avg.sync():
+                    g_loss.backward()
+            else:
                 g_loss.backward()
-        else:
-            g_loss.backward()
-            parallel.average_gradients(generator.parameters())
+                parallel.average_gradients(generator.parameters())
         g_optim.step()
         return d_loss, g_loss
 
@@ -93,10 +101,10 @@ def build_step(dev, B=16, L=24, rank=0, overlap=True):
 MIN_STEP_TFLOP = 0.68      # minimal work of one iteration at B=16, LR 24 (3.4e11 MACs)
 
 
-def cfg3(steps=10, warmup=3, B=16, L=24, dev=None, dist=None, rank=0, world=1, overlap=True, host_profile=False):
+def cfg3(steps=10, warmup=3, B=16, L=24, dev=None, dist=None, rank=0, world=1, overlap=True, host_profile=False, literal=False):
     """Time `steps` SRGAN iterations.  Returns the record dict (rank 0 prints it in main())."""
     dev = dev or torch.device("cuda:0")
-    step = build_step(dev, B, L, rank, overlap)
+    step = build_step(dev, B, L, rank, overlap, literal)
 
     def barrier():
         torch.cuda.synchronize()
@@ -133,7 +141,10 @@ def cfg3(steps=10, warmup=3, B=16, L=24, dev=None, dist=None, rank=0, world=1, o
            "dtype": "f32", "data": "synthetic", "scaling": "weak",
            "config": {"workload": f"SRGAN step P/mode.py:148-179, per GPU LR {B}x3x{L}x{L} -> HR {4*L}, "
                                   f"D patch {4*L}, VGG19-shaped frozen stack, Adam x2",
-                      "gradient_exchange": "overlapped (GradientAverager.sync)" if overlap else "after backward"},
+                      "gradient_exchange": "overlapped (GradientAverager.sync)" if overlap else "after backward",
+                      "iteration": "reference-literal (wasted G backward in the D step and D weight gradients in the G step kept)"
+                                   if literal else "as srmi.mode.train: G output detached for the D step, no D weight gradients in "
+                                   "the G step (bit-equal results, tests/test_mode_train_gpu.py)"},
            "d_loss": round(float(d_loss.detach()), 5), "g_loss": round(float(g_loss.detach()), 5)}
     if B == 16 and L == 24:
         tf = MIN_STEP_TFLOP / (ms * 1e-3)
@@ -149,6 +160,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--lr-size", type=int, default=24)
     ap.add_argument("--no-overlap", action="store_true", help="exchange gradients after backward (average_gradients)")
+    ap.add_argument("--literal", action="store_true", help="the reference's loop body word for word (its wasted backward work kept)")
     ap.add_argument("--host-profile", action="store_true", help="cProfile of the timed steps' enqueue path (main thread) to stderr")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -161,7 +173,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
-    rec = cfg3(args.steps, args.warmup, args.batch, args.lr_size, dev, dist, rank, world, not args.no_overlap, args.host_profile)
+    rec = cfg3(args.steps, args.warmup, args.batch, args.lr_size, dev, dist, rank, world, not args.no_overlap, args.host_profile, args.literal)
     if rank == 0:
         print(json.dumps(rec), flush=True)
     if dist is not None:
