@@ -24,7 +24,7 @@ Extra objects on the JSON line:
                  bf16 (ms, TFLOP/s, fraction of peak), cfg5 tiled 960x540 frame (ms/frame, MP/s).  --no-secondary skips it.
 
 `--workload cfg5` (with any --gpus N) switches the timed step to BASELINE config 5: a stream of 960x540 frames, each cut into
-8 LR tiles of 270x240 + 8 px halo that are dealt round-robin to the ranks (srmi.tiling.shard, no collective); a step =
+2 x 4 LR tiles of equal extended shape 278x252 (8 px halo) that are dealt round-robin to the ranks (srmi.tiling.shard, no collective); a step =
 one frame; value = useful output MP/s (halo pixels not counted); total work is fixed as N grows ("scaling": "strong").
 """
 from __future__ import annotations
@@ -287,11 +287,11 @@ def run_cfg5(args, dev, dist, rank, world):
         torch.cuda.synchronize()
     with torch.no_grad():
         for _ in range(args.warmup):
-            sr_tiled(gen, frame, tile=(270, 240), halo=8, rank=rank, world=world, out=out)
+            sr_tiled(gen, frame, halo=8, grid=(2, 4), rank=rank, world=world, out=out)
         barrier()
         t0 = time.perf_counter()
         for _ in range(steps):
-            _, ntiles = sr_tiled(gen, frame, tile=(270, 240), halo=8, rank=rank, world=world, out=out)
+            _, ntiles = sr_tiled(gen, frame, halo=8, grid=(2, 4), rank=rank, world=world, out=out)
         barrier()
         elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(elapsed, dist, dev)
@@ -304,8 +304,9 @@ def run_cfg5(args, dev, dist, rank, world):
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "bf16" if args.compute == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": "cfg5: tiled SRResNet x4 inference, 960x540 -> 3840x2160 frames, 8 LR tiles of 270x240 + 8 px "
-                                   "halo per frame dealt round-robin to the ranks, no collective; useful pixels only",
+            "config": {"workload": "cfg5: tiled SRResNet x4 inference, 960x540 -> 3840x2160 frames, 2 x 4 LR tiles per frame of "
+                                   "equal extended shape 278x252 (8 px halo) dealt round-robin to the ranks, no collective; "
+                                   "useful pixels only",
                        "tiles_per_frame": 8, "tiles_rank0": ntiles, "parallelism": f"tile-sharded x{world}, no collective"},
             "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS * world, "unit": "TFLOP/s",
                          "frac": round(tf / (PEAK_BF16_TFLOPS * world), 4), "traffic": None,

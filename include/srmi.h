@@ -196,7 +196,11 @@ int srmi_conv2d_can_fuse(const srmi_conv_args* conv1, const srmi_conv_args* conv
  * (conv2->d.H/W = 2x conv1's).  conv1's output tensor is never written: conv1->y is ignored (may be any non-aliasing
  * pointer), conv2->x is ignored.  The last conv's nine tap sums are accumulated in int32 fixed point (2^-18 units)
  * in LDS, so the result is the same for every run and every tiling; it differs from the two-launch path by that
- * quantisation (<= 2e-5 on the pre-activation) and by f32 summation order only.  Replaces the second `Upsampler`
+ * quantisation (<= 2e-5 on the pre-activation) and by f32 summation order only.  RANGE: each of the nine tap
+ * contributions to an output value is clamped to +-900 before the fixed-point conversion (9 x 900 x 2^18 < 2^31); a
+ * network whose last conv has tap sums beyond that (pre-activations in the thousands: tanh / sigmoid saturated long
+ * before) saturates silently here and would differ from the two-launch path - run such a pair as two launches (do
+ * not set SRMI_CONV_FUSE_NEXT on conv1; Python: `srmi.engine.set_fuse_tail(False)`).  Replaces the second `Upsampler`
  * + `last_conv` + tanh of `Generator.forward` (P/ops.py:74-78, P/srgan_model.py:36-37). */
 int srmi_conv2d_fwd_pair(const srmi_conv_args* conv1, const srmi_conv_args* conv2, void* stream);
 
@@ -264,6 +268,10 @@ int srmi_mse_loss(const float* a, const float* b, size_t n, float* out, void* ws
  * SRMI_REDUCE_WS_BYTES (16 KiB) file-scope device array of the library (one copy per GPU, held until the process
  * ends; its address is resolved once per device on the first call there).  The call enqueues two kernels on `stream`
  * and calls no hipMalloc / hipFree / allocating routine.  n > SRMI_NOALLOC_MAX_ELEMS is rejected with SRMI_EINVAL.
+ * The FIRST call on each device resolves the array's address with hipGetSymbolAddress, which is not a capturable
+ * operation: make one call per device outside graph capture first (any n >= 0; the result can be discarded).
+ * `stream` must belong to the CURRENT device (hipGetDevice): the scratch copy is chosen by the current device and a
+ * stream of another GPU is rejected with SRMI_EINVAL rather than run against the wrong GPU's array.
  * Every call on a GPU shares that GPU's array: calls that overlap in time on one GPU (two streams, two threads) RACE
  * on it - serialise them on one stream, or use srmi_mse_loss with a workspace per stream.  The array needs no clearing
  * between calls (every slot read was written by the same call).  Result bit-identical to srmi_mse_loss. */

@@ -276,9 +276,9 @@ int y_metrics(const float* sr, const float* gt, int nimg, int H, int W, int gt_H
 
 // ---- the one entry point that allocates nothing and takes no workspace (include/srmi.h) -----------------------------
 // srmi_mse_loss_noalloc = srmi_mse_loss with the per-workgroup f64 partials kept in a file-scope device array instead of
-// a caller workspace.  `srmi_noalloc_scratch` below is the HOST-SIDE STAND-IN of that array: its device address is
-// resolved once per device with hipGetSymbolAddress (each GPU holds its own copy at its own address) and only that
-// pointer is ever handed to a kernel.
+// a caller workspace.  In host code the NAME `srmi_noalloc_scratch` is not a device address (passing it to a kernel
+// compiles and then faults): the array's device address is resolved once per device with hipGetSymbolAddress (each
+// GPU holds its own copy at its own address) and only that pointer is ever handed to a kernel.
 static __device__ __align__(256) unsigned char srmi_noalloc_scratch[SRMI_REDUCE_WS_BYTES];
 
 namespace srmi {
@@ -318,6 +318,13 @@ extern "C" int srmi_mse_loss_noalloc(const float* a, const float* b, size_t n, f
     void* ws = nullptr;
     int rc = noalloc_scratch(&ws);
     if (rc) return rc;
+    if (stream) {          // the scratch copy belongs to the CURRENT device: refuse a stream that lives on another GPU
+        int sdev = -1, cdev = -1;
+        if (hipStreamGetDevice((hipStream_t)stream, &sdev) == hipSuccess && hipGetDevice(&cdev) == hipSuccess && sdev != cdev) {
+            set_error("mse_loss_noalloc: stream belongs to device %d, current device is %d", sdev, cdev);
+            return SRMI_EINVAL;
+        }
+    }
     // nothing to clear: stage 1 overwrites slots 0..nb-1 and stage 2 reads exactly those slots
     return pair_loss(OP_SQDIFF, a, b, n, out, ws, (hipStream_t)stream);
 }

@@ -19,6 +19,7 @@ There is no fallback to ATen convolution / batch-norm kernels anywhere in this f
 from __future__ import annotations
 
 import ctypes as C
+import threading
 import weakref
 
 import torch
@@ -86,14 +87,16 @@ class _Workspace:
 
     def __init__(self):
         self.bufs = {}
+        self.lock = threading.Lock()     # forward (caller's thread) and backward (autograd engine threads) both come here
 
     def get(self, nbytes, device):
         if nbytes == 0:
             return None
         key = (device, Fn.stream_ptr(device))
-        t = self.bufs.get(key)
-        if t is None or t.numel() < nbytes:
-            t = self.bufs[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        with self.lock:
+            t = self.bufs.get(key)
+            if t is None or t.numel() < nbytes:
+                t = self.bufs[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         if _POISON:        # SRMI_POISON_WS=1 (tests): NaN-fill before every use - a kernel that reads a slot it did not write shows
             t.view(torch.float32).fill_(float("nan"))
         return t
@@ -139,15 +142,19 @@ class _ConvPlan:
 
 
 _PLANS = {}
+_PLANS_LOCK = threading.Lock()
 
 
 def _conv_plan(N, H, W, Cin, Cout, kh, kw, stride, pad):
     key = (N, H, W, Cin, Cout, kh, kw, stride, pad)
     pl = _PLANS.get(key)
     if pl is None:
-        if len(_PLANS) > 4096:
-            _PLANS.clear()
-        pl = _PLANS[key] = _ConvPlan(key)
+        with _PLANS_LOCK:
+            pl = _PLANS.get(key)
+            if pl is None:
+                if len(_PLANS) > 4096:
+                    _PLANS.clear()
+                pl = _PLANS[key] = _ConvPlan(key)
     return pl
 
 
@@ -161,6 +168,7 @@ class _PackCache:
 
     def __init__(self):
         self.entries = {}
+        self.lock = threading.Lock()
 
     def get(self, kind, w, build):
         base = w._base if w._base is not None else w
@@ -169,9 +177,10 @@ class _PackCache:
         if hit is not None and hit[0]() is base and hit[1] == (base._version, base.data_ptr()):
             return hit[2]
         packed = build()
-        if len(self.entries) > 4096:           # dead entries of discarded models
-            self.entries = {k: v for k, v in self.entries.items() if v[0]() is not None}
-        self.entries[key] = (weakref.ref(base), (base._version, base.data_ptr()), packed)
+        with self.lock:
+            if len(self.entries) > 4096:           # dead entries of discarded models
+                self.entries = {k: v for k, v in self.entries.items() if v[0]() is not None}
+            self.entries[key] = (weakref.ref(base), (base._version, base.data_ptr()), packed)
         return packed
 
     def clear(self):

@@ -126,6 +126,13 @@ class _Seq:
         for i, (desc, x, wp, scale, shift, alpha, residual, y, fuse_next) in enumerate(self.layers):
             Fn.fill_args(arr[i], desc, x if x is not None else 0, wp, scale, shift, alpha, residual, y)
             arr[i].flags = L.CONV_FUSE_NEXT if fuse_next else 0
+        if not _FUSE_TAIL:
+            # the fused tail clamps each tap contribution of the last conv to +-900 (int32 fixed-point accumulation,
+            # include/srmi.h SRMI_FUSE_UPTAIL): a net whose last conv is not range-bounded runs the pair as two launches
+            lib = L.load()
+            for i in range(n - 1):
+                if (arr[i].flags & L.CONV_FUSE_NEXT) and lib.srmi_conv2d_can_fuse(C.byref(arr[i]), C.byref(arr[i + 1])) == 2:
+                    arr[i].flags = 0
         return arr, n
 
     @staticmethod
@@ -144,6 +151,17 @@ class _Seq:
                 out.append((kernels[i], i, 1))
                 i += 1
         return out
+
+
+_FUSE_TAIL = True
+
+
+def set_fuse_tail(enabled: bool):
+    """False: plans built from now on run `Upsampler` conv + last conv as TWO launches instead of the fused tail
+    (whose int32 fixed-point accumulation clamps each tap contribution of the last conv to +-900, include/srmi.h).
+    Plans already cached keep their form: call srmi.engine.invalidate(module) to rebuild them."""
+    global _FUSE_TAIL
+    _FUSE_TAIL = bool(enabled)
 
 
 class GeneratorPlan:

@@ -37,14 +37,48 @@ def plan_tiles(H, W, tile_h, tile_w, halo):
     return tiles
 
 
+def _equal_cuts(L, n, halo):
+    """Cut [0, L) into n core intervals whose EXTENDED lengths (core + halo on every side that has a neighbour) are as
+    equal as integers allow: border tiles get `halo` more core pixels than interior ones."""
+    if n <= 1 or L < n:
+        return [(0, L)]
+    total = L + 2 * halo * (n - 1)                  # sum of the extended lengths
+    base, extra = divmod(total, n)
+    cuts, pos = [], 0
+    for i in range(n):
+        ext = base + (1 if i < extra else 0)
+        core = ext - (halo if i in (0, n - 1) else 2 * halo)
+        core = max(1, min(core, L - pos - (n - 1 - i)))
+        end = L if i == n - 1 else pos + core
+        cuts.append((pos, end))
+        pos = end
+    return cuts
+
+
+def plan_tiles_equal(H, W, ny, nx, halo):
+    """Like plan_tiles, for an ny x nx grid whose tiles all have (nearly) the SAME extended shape, so that every tile
+    of a frame goes through ONE launch sequence as one batch (plan_tiles' equal core tiles give border tiles a smaller
+    extended shape than interior ones: 960x540 in 2 x 4 tiles with an 8-pixel halo is two batches of four, 278x248 and
+    278x256; here it is one batch of eight 278x252 tiles)."""
+    if ny <= 0 or nx <= 0 or halo < 0:
+        raise ValueError("grid must be positive and halo non-negative")
+    tiles = []
+    for (y0, y1) in _equal_cuts(H, ny, halo):
+        for (x0, x1) in _equal_cuts(W, nx, halo):
+            tiles.append((y0, y1, x0, x1, max(y0 - halo, 0), min(y1 + halo, H), max(x0 - halo, 0), min(x1 + halo, W)))
+    return tiles
+
+
 @torch.no_grad()
-def sr_tiled(fn, lr, tile=(270, 240), halo=8, scale=4, rank=0, world=1, out=None):
+def sr_tiled(fn, lr, tile=(270, 240), halo=8, scale=4, rank=0, world=1, out=None, grid=None):
     """Run `fn(lr_tiles) -> (sr, feat)` (a Generator) over this rank's tiles of `lr` (N,C,H,W).
 
     Returns (out, n_tiles): `out` is (N,C,scale*H,scale*W) with this rank's core regions filled (zeros
     elsewhere when world > 1: summing the ranks' outputs, or writing them to disjoint files, gives the frame)."""
     N, C, H, W = lr.shape
-    tiles = shard(plan_tiles(H, W, tile[0], tile[1], halo), rank, world)
+    # grid=(ny, nx): equal EXTENDED tile shapes (one batch per frame); otherwise equal core tiles of `tile` pixels
+    plan = plan_tiles_equal(H, W, grid[0], grid[1], halo) if grid is not None else plan_tiles(H, W, tile[0], tile[1], halo)
+    tiles = shard(plan, rank, world)
     if out is None:
         out = torch.zeros((N, C, scale * H, scale * W), dtype=torch.float32, device=lr.device)
     groups = defaultdict(list)

@@ -68,6 +68,25 @@ def test_cfg4_rrdb23_bf16_at_config_size(golden_dir):
     assert psnr >= 55.0          # measured 66.6 dB, max|d| 4.3e-3
 
 
+def test_cfg5_equal_extended_tiles_match_generator_on_crops():
+    """The same property for the one-batch plan (`grid=(2, 4)`: eight 278 x 252 extended tiles through ONE launch
+    sequence - what bench.py's cfg5 legs time): every tile's core region is bit-identical to `Generator` on that crop."""
+    gen = Generator(num_block=16)
+    gen.load_state_dict(O.to_torch(W.generator_weights(seed=0, num_block=16)))
+    gen = gen.to(DEV).eval().set_compute("bf16")
+    x = torch.from_numpy(W.lr_input((1, 3, 540, 960), seed=77)).to(DEV)
+    plan = tiling.plan_tiles_equal(540, 960, 2, 4, 8)
+    assert {(t[5] - t[4], t[7] - t[6]) for t in plan} == {(278, 252)}
+    with torch.no_grad():
+        stitched, n = tiling.sr_tiled(gen, x, halo=8, grid=(2, 4))
+        assert n == 8 and stitched.shape == (1, 3, 2160, 3840)
+        for (y0, y1, x0, x1, ey0, ey1, ex0, ex1) in plan:
+            sr, _ = gen(x[:, :, ey0:ey1, ex0:ex1].contiguous())
+            oy, ox = 4 * (y0 - ey0), 4 * (x0 - ex0)
+            assert torch.equal(sr[:, :, oy:oy + 4 * (y1 - y0), ox:ox + 4 * (x1 - x0)],
+                               stitched[:, :, 4 * y0:4 * y1, 4 * x0:4 * x1]), (y0, x0)
+
+
 @pytest.mark.parametrize("compute", ["bf16", "fp32"])
 def test_cfg5_tiles_match_generator_on_crops(compute):
     """BASELINE config 5: one 960x540 LR frame, 4 x 2 core tiles of 240 x 270 with an 8-px halo, 16-block generator.

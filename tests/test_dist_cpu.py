@@ -66,6 +66,25 @@ def test_plan_tiles_cover_exactly_once():
     assert len(tiling.plan_tiles(540, 960, 270, 240, 8)) == 8      # BASELINE config 5: one tile per GPU
 
 
+def test_equal_extended_tiles_cover_exactly_once_and_share_a_shape():
+    for (H, W, ny, nx, halo) in [(540, 960, 2, 4, 8), (17, 23, 3, 4, 2), (100, 100, 1, 1, 8), (64, 64, 5, 3, 4), (9, 50, 1, 6, 3)]:
+        cover = torch.zeros(H, W, dtype=torch.int32)
+        plan = tiling.plan_tiles_equal(H, W, ny, nx, halo)
+        assert len(plan) == ny * nx
+        for (y0, y1, x0, x1, ey0, ey1, ex0, ex1) in plan:
+            cover[y0:y1, x0:x1] += 1
+            assert 0 <= ey0 <= y0 < y1 <= ey1 <= H and 0 <= ex0 <= x0 < x1 <= ex1 <= W
+        assert int(cover.min()) == 1 and int(cover.max()) == 1
+        hs, ws = {t[5] - t[4] for t in plan}, {t[7] - t[6] for t in plan}
+        assert max(hs) - min(hs) <= 1 and max(ws) - min(ws) <= 1
+    assert {(t[5] - t[4], t[7] - t[6]) for t in tiling.plan_tiles_equal(540, 960, 2, 4, 8)} == {(278, 252)}   # cfg5: ONE batch
+    lr = torch.rand(1, 3, 20, 31)
+    out, n = tiling.sr_tiled(_stub_generator, lr, halo=2, grid=(2, 3))
+    assert n == 6 and torch.equal(out, _stub_generator(lr)[0])
+    parts = [tiling.sr_tiled(_stub_generator, lr, halo=2, grid=(2, 3), rank=r, world=2)[0] for r in range(2)]
+    assert torch.equal(parts[0] + parts[1], _stub_generator(lr)[0])
+
+
 def test_shard_is_a_partition():
     units = list(range(11))
     parts = [tiling.shard(units, r, 4) for r in range(4)]

@@ -266,3 +266,26 @@ def test_data_mutation_needs_invalidate():
         gen.last_conv.body[0].weight.mul_(2.0)          # versioned write: detected without invalidate()
         c, _ = gen(x)
         assert torch.allclose(a, c, atol=1e-6)
+
+
+def test_fused_tail_can_be_switched_off(golden_dir):
+    """srmi.engine.set_fuse_tail(False): the second Upsampler + last_conv run as two launches (no int32 fixed-point
+    accumulation, no +-900 clamp of its tap contributions: include/srmi.h SRMI_FUSE_UPTAIL); same result to 4e-5."""
+    from srmi import engine
+    g = _load(golden_dir, "gen_b2_2x3x8x8.npz")
+    x = torch.from_numpy(g["x"]).to(DEV)
+    try:
+        gen = _make_gen(g, "bf16")
+        with torch.no_grad():
+            fused, _ = gen(x)
+        labels = [u[0] for u in gen._plans.get(gen, x.shape[0], x.shape[2], x.shape[3], 1).launches]
+        assert "upfuse_bf16" in labels
+        engine.set_fuse_tail(False)
+        engine.invalidate(gen)
+        with torch.no_grad():
+            plain, _ = gen(x)
+        labels = [u[0] for u in gen._plans.get(gen, x.shape[0], x.shape[2], x.shape[3], 1).launches]
+        assert "upfuse_bf16" not in labels and "c64_thin_bf16" in labels
+        assert float((fused - plain).abs().max()) <= 4e-5
+    finally:
+        engine.set_fuse_tail(True)
