@@ -22,7 +22,12 @@ typedef __bf16 b3h_bf16x2 __attribute__((ext_vector_type(2)));
 
 constexpr int B3H_T = 8;                     // output tile side
 constexpr int B3H_HS = B3H_T + 2;            // halo tile side
-constexpr int B3H_PITCH = 72;                // bf16 per LDS row (64 channels + 8: 144 bytes)
+constexpr int B3H_PITCH = 72;                // bf16 per LDS pixel (64 channels + 8: 144 bytes = 9 chunks of 16 B)
+// bf16 per LDS halo ROW: 104 chunks of 16 B (10 pixels use 90).  A wave's A-operand read (ds_read_b128) is serviced in
+// groups of 16 lanes, each group = four 4-pixel half rows of four consecutive tile rows; with 9 chunks per pixel and 104
+// per row the 16 pixels of every group - for every tap - land on 16 different 16-byte slots of the 256-byte bank row.
+// With rows packed at 90 chunks two of the four half rows coincided (SQ_LDS_BANK_CONFLICT 5 cycles per LDS-active cycle).
+constexpr int B3H_ROWP = 104 * 8;
 
 __device__ __forceinline__ void b3h_split2(float x0, float x1, unsigned& hi, unsigned& mid, unsigned& lo) {
     hi = __builtin_bit_cast(unsigned, __builtin_convertvector(b3h_f32x2{x0, x1}, b3h_bf16x2));
@@ -41,7 +46,8 @@ struct B3hParams {
 };
 
 __global__ __launch_bounds__(256) void conv_b3h_kernel(B3hParams p) {
-    __shared__ __attribute__((aligned(16))) unsigned short As[3][B3H_HS * B3H_HS][B3H_PITCH];
+    __shared__ __attribute__((aligned(16))) unsigned short As[3][B3H_HS * B3H_ROWP];
+    auto at = [](int hy, int hx) { return hy * B3H_ROWP + hx * B3H_PITCH; };      // element offset of halo pixel (hy, hx) in a plane
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int i = lane & 31, h = lane >> 5;
@@ -85,12 +91,14 @@ __global__ __launch_bounds__(256) void conv_b3h_kernel(B3hParams p) {
         const int idx = tid + 256 * l;
         if (idx < PIECES) {
             const int hp = idx >> 4, k = 4 * (idx & 15);
+            const int hy = hp / B3H_HS, hx = hp - hy * B3H_HS;
+            const int o = at(hy, hx) + k;
             unsigned hi[2], mid[2], lo[2];
             b3h_split2(ra[l][0], ra[l][1], hi[0], mid[0], lo[0]);
             b3h_split2(ra[l][2], ra[l][3], hi[1], mid[1], lo[1]);
-            *(u32x2*)&As[0][hp][k] = u32x2{hi[0], hi[1]};
-            *(u32x2*)&As[1][hp][k] = u32x2{mid[0], mid[1]};
-            *(u32x2*)&As[2][hp][k] = u32x2{lo[0], lo[1]};
+            *(u32x2*)&As[0][o] = u32x2{hi[0], hi[1]};
+            *(u32x2*)&As[1][o] = u32x2{mid[0], mid[1]};
+            *(u32x2*)&As[2][o] = u32x2{lo[0], lo[1]};
         }
     }
     __syncthreads();
@@ -109,12 +117,12 @@ __global__ __launch_bounds__(256) void conv_b3h_kernel(B3hParams p) {
         if (tap + 1 < 9) load_b(tap + 1, bq[(tap + 1) & 1]);
         const int ky = tap / 3, kx = tap - 3 * ky;
         // forward: input pixel = o - 1 + k; dgrad: o + 1 - k  (halo origin = o - 1 in both)
-        const int hp = p.transposed ? (py + 2 - ky) * B3H_HS + px + 2 - kx : (py + ky) * B3H_HS + px + kx;
+        const int hp = p.transposed ? at(py + 2 - ky, px + 2 - kx) : at(py + ky, px + kx);
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             b3h_bf16x8 av[3];
 #pragma unroll
-            for (int pl = 0; pl < 3; ++pl) av[pl] = *(const b3h_bf16x8*)&As[pl][hp][16 * s + 8 * h];
+            for (int pl = 0; pl < 3; ++pl) av[pl] = *(const b3h_bf16x8*)&As[pl][hp + 16 * s + 8 * h];
 #pragma unroll
             for (int t = 0; t < 6; ++t) {
                 const b3h_bf16x8 bv = __builtin_bit_cast(b3h_bf16x8, bq[tap & 1][s][PB[t]]);
