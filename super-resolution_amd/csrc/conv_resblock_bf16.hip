@@ -231,9 +231,11 @@ __global__ __launch_bounds__(NW * 64, WGPC) void resblock_c64_kernel(ResBlockPar
     auto handoff = [&](int g) {
         if ((g + 1) % KS != 0) return;
         const int S = (g + 1) / KS;
-        const bool more = SLOTS >= 4 && S + 1 < NS;         // slot S+1 exists and may stay in flight
+        // slots S+1 .. S+SLOTS-3 (those that exist) may stay in flight
+        const int ahead = (SLOTS - 3) < (NS - 1 - S) ? (SLOTS - 3) : (NS - 1 - S);
         if (!(kdbg & (1 << 17))) {       // (timing experiment: no wait for the weights)
-            if (more) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (SLOTS - 3)) : "memory");
+            if (SLOTS >= 5 && ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * 2) : "memory");
+            else if (SLOTS >= 4 && ahead >= 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * 1) : "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         if (!(kdbg & (1 << 18))) __builtin_amdgcn_s_barrier();      // (timing experiment: no hand-off barrier)
@@ -545,6 +547,13 @@ int resblock_launch(const srmi_conv_args& a1, const srmi_conv_args& a2, hipStrea
         // at this tile: 157 KB) - 29.4 vs 29.75 us per launch in three alternating runs; SRMI_DBG bit 22: the K-step ring
         // (four tap slots with an 8-pixel pitch, 149 KB: 29.0 vs 28.2 us - the narrower pitch costs more than the deeper ring gains)
         if (p.dbg & (1 << 22)) hipLaunchKernelGGL((resblock_c64_kernel<12, 3, 8, 4, 1, 1>), dim3((unsigned)nb48), dim3(512), 0, s, p);
+#ifdef SRMI_ABLATE
+        // round 3, same call: 56-pixel pitch with 4 / 5 / 3 tap slots (149-157 KB): 24.8-25.3 us each against 25.2-25.3 for
+        // the product form - with the conflict-free swizzle the pitch costs nothing, and the ring depth buys nothing
+        else if (p.exp & 32) hipLaunchKernelGGL((resblock_c64_kernel<12, 3, 8, 4, 1, 2, 8>), dim3((unsigned)nb48), dim3(512), 0, s, p);
+        else if (p.exp & 64) hipLaunchKernelGGL((resblock_c64_kernel<12, 3, 8, 5, 1, 2, 8>), dim3((unsigned)nb48), dim3(512), 0, s, p);
+        else if (p.exp & 128) hipLaunchKernelGGL((resblock_c64_kernel<12, 3, 8, 3, 1, 2, 8>), dim3((unsigned)nb48), dim3(512), 0, s, p);
+#endif
         else {
 #ifdef SRMI_ABLATE
             p.stamps = next_stamp_slot((unsigned)nb48);
