@@ -27,8 +27,8 @@
 extern "C" {
 #endif
 
-#define SRMI_VERSION 114 /* 0.1.4: bn_train_stats counts num_batches_tracked, epilogue_bwd zero-fills the BN-fed bias gradient;
-                            srmi_conv2d_kernel_name reports the f32 kernel that runs */
+#define SRMI_VERSION 115 /* 0.1.5: srmi_adam_step takes double hyper-parameters (0.1.4: bn_train_stats counts num_batches_tracked, epilogue_bwd zero-fills the BN-fed bias gradient;
+                            srmi_conv2d_kernel_name reports the f32 kernel that runs) */
 
 /* error codes */
 #define SRMI_OK 0
@@ -390,10 +390,14 @@ int srmi_bce_loss_bwd(const float* p, const float* t, const float* gout, size_t 
 int srmi_tv_loss_bwd(const float* x, const float* gout, int32_t N, int32_t C, int32_t H, int32_t W, float weight,
                      float* dx, void* stream);
 
-/* One Adam update of a flat f32 parameter buffer (torch.optim.Adam defaults; P/mode.py:90, :138-139);
- * `step` is the 1-based step count used for the bias corrections. */
-int srmi_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
-                   float beta1, float beta2, float eps, int32_t step, void* stream);
+/* One Adam update of a flat f32 parameter buffer (torch.optim.Adam defaults: no amsgrad, no weight decay; P/mode.py:90,
+ * :132); `step` is the 1-based step count used for the bias corrections.  The hyper-parameters are doubles, as Python
+ * holds them: the scalars the update uses (1 - beta1, 1 - beta2, lr / (1 - beta1^step), sqrt(1 - beta2^step)) are formed
+ * in double and rounded to f32 once, as torch.optim.Adam forms them - the update then follows torch's order
+ * (lerp, mul + addcmul, sqrt / bc2 + eps, addcdiv) and agrees with it to an ulp.  One launch for a whole model when its
+ * parameters, gradients and moments live in flat buffers (srmi/optim.py) instead of a dozen multi-tensor launches. */
+int srmi_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
+                   double beta1, double beta2, double eps, int32_t step, void* stream);
 
 #ifdef __cplusplus
 }

@@ -67,8 +67,8 @@ int maxpool_fwd(const float* x, float* y, int N, int H, int W, int C, hipStream_
 int maxpool_bwd(const float* x, const float* dy, float* dx, int N, int H, int W, int C, hipStream_t s);
 int mse_bwd(const float* a, const float* b, const float* gout, size_t n, float* da, float* db, hipStream_t s);
 int bce_bwd(const float* p, const float* t, const float* gout, size_t n, float* dp, hipStream_t s);
-int adam_step(float* param, const float* grad, float* m, float* v, size_t n, float lr, float beta1, float beta2,
-              float eps, int step, hipStream_t s);
+int adam_step(float* param, const float* grad, float* m, float* v, size_t n, double lr, double beta1, double beta2,
+              double eps, int step, hipStream_t s);
 int tv_bwd(const float* x, const float* gout, int N, int C, int H, int W, float weight, float* dx, hipStream_t s);
 size_t generic_dgrad_packed_bytes(const srmi_conv_desc& d);
 int generic_dgrad_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s);
@@ -638,8 +638,8 @@ int srmi_tv_loss_bwd(const float* x, const float* gout, int32_t N, int32_t C, in
     return tv_bwd(x, gout, N, C, H, W, weight, dx, (hipStream_t)stream);
 }
 
-int srmi_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, float lr,
-                   float beta1, float beta2, float eps, int32_t step, void* stream) {
+int srmi_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, size_t n, double lr,
+                   double beta1, double beta2, double eps, int32_t step, void* stream) {
     if (!param || !grad || !exp_avg || !exp_avg_sq || step < 1) {
         set_error("adam_step: NULL argument or step < 1");
         return SRMI_EINVAL;

@@ -43,6 +43,7 @@ struct UpFuseParams {
     int tiles_x, tiles_y;
     int act7; float act7_param;
     int vec4;                              // y 16-byte aligned and 2W % 4 == 0: whole-quad stores
+    int exp;                               // SRMI_EXP (ablation build only): 256 skip half of the LDS adds, 512 skip all, 1024 exec-mask them to lanes pl < 2
 };
 
 constexpr int UF_TAP_BYTES = 8192;
@@ -324,6 +325,10 @@ __global__ __launch_bounds__(NW * 64, 1) void upfuse_kernel(UpFuseParams p) {
                 for (int e = 0; e < 4; ++e) {
                     const float f0 = __builtin_amdgcn_fmed3f(d0[e], -UF_CLAMP, UF_CLAMP) * UF_FIX;
                     const float f1 = __builtin_amdgcn_fmed3f(d1[e], -UF_CLAMP, UF_CLAMP) * UF_FIX;
+#ifdef SRMI_ABLATE
+                    if ((p.exp & 512) || ((p.exp & 256) && e >= 2)) { asm volatile("" :: "v"(f0), "v"(f1)); continue; }
+                    if ((p.exp & 1024) && pl >= 2) { asm volatile("" :: "v"(f0), "v"(f1)); continue; }
+#endif
                     atomicAdd(dst + ooff[0][e], (int)__builtin_rintf(f0));
                     atomicAdd(dst + ooff[1][e], (int)__builtin_rintf(f1));     // (zero rows: zero weights, add 0)
                 }
@@ -408,6 +413,7 @@ int upfuse_launch(const srmi_conv_args& a1, const srmi_conv_args& a2, hipStream_
     p.y = (float*)a2.y;
     p.N = d1.N; p.H = d1.H; p.W = d1.W; p.in_cs = d1.in_cstride ? d1.in_cstride : 64;
     p.act7 = d2.act; p.act7_param = d2.act_param;
+    p.exp = exp_flags();
     p.vec4 = (((uintptr_t)a2.y & 15) == 0 && ((2 * d1.W) & 3) == 0) ? 1 : 0;
     if (d1.N == 0 || d1.H == 0 || d1.W == 0) return SRMI_OK;
     p.tiles_x = (d1.W + 23) / 24; p.tiles_y = (d1.H + 23) / 24;

@@ -482,13 +482,14 @@ __global__ __launch_bounds__(CH_BLOCK) void tv_bwd_kernel(const float* __restric
 // ---- Adam (torch.optim.Adam defaults: no amsgrad, weight_decay 0; P/mode.py:90, :138-139) -------------
 __global__ __launch_bounds__(CH_BLOCK) void adam_kernel(float* __restrict__ param, const float* __restrict__ grad,
                                                         float* __restrict__ m, float* __restrict__ v, size_t n,
-                                                        float lr, float beta1, float beta2, float eps, float bc1,
+                                                        float w1, float beta2, float w2, float eps, float step_size,
                                                         float bc2_sqrt) {
-    const float step_size = lr / bc1;
+    // torch.optim.Adam (foreach form): exp_avg.lerp_(g, 1 - b1); exp_avg_sq.mul_(b2).addcmul_(g, g, value = 1 - b2);
+    // denom = (exp_avg_sq.sqrt() / bc2_sqrt).add_(eps); p.addcdiv_(exp_avg, denom, value = -step_size)
     for (size_t i = (size_t)blockIdx.x * CH_BLOCK + threadIdx.x; i < n; i += (size_t)gridDim.x * CH_BLOCK) {
         const float g = grad[i];
-        const float mi = m[i] + (g - m[i]) * (1.f - beta1);          // lerp, as torch
-        const float vi = v[i] * beta2 + (1.f - beta2) * g * g;
+        const float mi = m[i] + w1 * (g - m[i]);                  // lerp, weight < 0.5
+        const float vi = v[i] * beta2 + w2 * g * g;
         m[i] = mi; v[i] = vi;
         const float denom = sqrtf(vi) / bc2_sqrt + eps;
         param[i] -= step_size * (mi / denom);
@@ -636,13 +637,14 @@ int tv_bwd(const float* x, const float* gout, int N, int C, int H, int W, float 
     return hip_check(hipGetLastError(), "tv_bwd_kernel");
 }
 
-int adam_step(float* param, const float* grad, float* m, float* v, size_t n, float lr, float beta1, float beta2,
-              float eps, int step, hipStream_t s) {
+int adam_step(float* param, const float* grad, float* m, float* v, size_t n, double lr, double beta1, double beta2,
+              double eps, int step, hipStream_t s) {
     if (n == 0) return SRMI_OK;
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(CH_BLOCK), 0, s, param, grad, m, v, n, lr, beta1, beta2, eps,
-                       (float)bc1, (float)sqrt(bc2));
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    // every scalar in double first, rounded to f32 once (what torch's Python-side scalars go through)
+    hipLaunchKernelGGL(adam_kernel, dim3(ew_blocks(n)), dim3(CH_BLOCK), 0, s, param, grad, m, v, n, (float)(1.0 - beta1),
+                       (float)beta2, (float)(1.0 - beta2), (float)eps, (float)(lr / bc1), (float)sqrt(bc2));
     return hip_check(hipGetLastError(), "adam_kernel");
 }
 

@@ -133,8 +133,8 @@ SYMBOLS = {
     "srmi_bce_loss_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "srmi_tv_loss_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
                                    C.c_void_p, C.c_void_p]),
-    "srmi_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_float, C.c_float,
-                                 C.c_float, C.c_float, C.c_int32, C.c_void_p]),
+    "srmi_adam_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_double, C.c_double,
+                                 C.c_double, C.c_double, C.c_int32, C.c_void_p]),
 }
 REDUCE_WS_BYTES = 16384
 METRICS_MAX_BATCH = 256

@@ -21,6 +21,8 @@ of it visible in any parameter, buffer or loss value:
     `args.batch_size` rows (:138-139) and has no `drop_last`, so a ragged last batch (93 images = 5 x 16 + 13 in the
     bundled dataset) makes its BCELoss raise; here the last batch trains like the others;
   * `metrics_df.append` (removed in pandas 2) is replaced by rewriting the CSV from a list of rows;
+  * `optim.Adam` is srmi.optim.Adam: the same update (torch's arithmetic order, agreeing to an ulp per step) as one
+    launch per model over flat parameter / gradient / moment buffers instead of a dozen multi-tensor launches;
   * with torch.distributed initialised (one process per GPU) every rank draws its own batches and the two
     gradient exchanges of SURVEY 8e2 run inside `GradientAverager.sync()` blocks; rank 0 writes files.
 """
@@ -121,9 +123,10 @@ def train(args, images=None, vgg_net=None, log=print):
     `vgg19()` (whose ImageNet weights cannot be downloaded here: set SRMI_VGG19_WEIGHTS, or pass a module).
     Returns {"generator", "discriminator", "metrics", "pre_loss", "g_loss", "d_loss"}."""
     import torch.distributed as dist
-    import torch.optim as optim
+    import torch.optim.lr_scheduler as lr_scheduler
 
     from . import losses, parallel
+    from . import optim          # Adam as ONE launch per model over flat buffers (torch.optim.Adam's update to an ulp)
     from .dataset import Compose, augmentation, crop, mydata
     from .vgg19 import vgg19
 
@@ -210,7 +213,7 @@ def train(args, images=None, vgg_net=None, log=print):
 
     d_optim = optim.Adam(discriminator.parameters(), lr=1e-4)
     d_avg = parallel.GradientAverager(discriminator.parameters())
-    scheduler = optim.lr_scheduler.StepLR(g_optim, step_size=2000, gamma=0.1)
+    scheduler = lr_scheduler.StepLR(g_optim, step_size=2000, gamma=0.1)
 
     VGG_loss = losses.perceptual_loss(vgg_net)
     cross_ent = losses.BCELoss()

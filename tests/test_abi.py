@@ -29,7 +29,7 @@ def test_header_symbols_all_exported():
 
 def test_version_and_struct_layout():
     lib = L.load()
-    assert lib.srmi_version() == 114
+    assert lib.srmi_version() == 115
     assert C.sizeof(L.ConvDesc) == 24 * 4
     assert C.sizeof(L.ConvArgs) == 96 + 7 * 8 + 8
     assert L.ConvArgs.flags.offset == 152

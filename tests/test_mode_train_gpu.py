@@ -54,8 +54,10 @@ def _seed(s=11):
 
 def _reference_loop(args, images, vgg_net):
     """P/mode.py:75-179 restated with the reference's wasted work kept (labels sized from the batch, as train() does)."""
-    import torch.optim as optim
+    import torch.optim.lr_scheduler as lr_scheduler
     from srmi import losses
+    from srmi import optim          # the optimizer train() uses (agrees with torch.optim.Adam to an ulp per step:
+    #                                 tests/test_train_ops_gpu.py::test_flat_adam_tracks_torch_adam)
     from srmi.dataset import Compose, augmentation, crop, mydata
     from srmi.srgan_model import Discriminator, Generator
     dataset = mydata(in_memory=args.in_memory, transform=Compose([crop(args.scale, args.patch_size), augmentation()]),
@@ -77,7 +79,7 @@ def _reference_loop(args, images, vgg_net):
     discriminator = Discriminator(patch_size=args.patch_size * args.scale).to(DEV)
     discriminator.train()
     d_optim = optim.Adam(discriminator.parameters(), lr=1e-4)
-    scheduler = optim.lr_scheduler.StepLR(g_optim, step_size=2000, gamma=0.1)
+    scheduler = lr_scheduler.StepLR(g_optim, step_size=2000, gamma=0.1)
     VGG_loss, cross_ent, tv_loss = losses.perceptual_loss(vgg_net), losses.BCELoss(), losses.TVLoss()
     for _ in range(args.fine_train_epoch):
         scheduler.step()

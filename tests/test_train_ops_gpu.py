@@ -258,3 +258,39 @@ def test_training_forward_is_bit_deterministic():
     big = Fn.make_desc(16, 96, 96, 64, 64, 3)                             # plenty of pixels: no split, no workspace
     L.check(L.load().srmi_conv2d_workspace_bytes(C.byref(big), C.byref(n)))
     assert n.value == 0
+
+
+def test_flat_adam_tracks_torch_adam():
+    """srmi.optim.Adam (one launch over flat buffers) against torch.optim.Adam on the same gradients: 12 steps over a
+    model with a shared parameter, a StepLR decay in the middle and one step in which a parameter has no gradient.
+    Agreement to 2 ulp of the parameter magnitude per step (the scalars are formed as torch forms them; what can differ is
+    FMA contraction inside the two implementations)."""
+    from srmi import optim as srmi_optim
+    torch.manual_seed(3)
+    def make():
+        torch.manual_seed(3)
+        return nn.Sequential(nn.Conv2d(3, 16, 3), nn.PReLU(), nn.Conv2d(16, 8, 3), nn.Linear(8, 5)).to(DEV)
+    ma, mb = make(), make()
+    oa = torch.optim.Adam(ma.parameters(), lr=1e-3)
+    ob = srmi_optim.Adam(mb.parameters(), lr=1e-3)
+    sa = torch.optim.lr_scheduler.StepLR(oa, step_size=5, gamma=0.1)
+    sb = torch.optim.lr_scheduler.StepLR(ob, step_size=5, gamma=0.1)
+    # the parameters now live in one flat buffer, in order
+    flat = ob._flat[0]["p"]
+    assert all(p.data_ptr() == flat.data_ptr() + 4 * off for p, off in zip(ob._flat[0]["params"], ob._flat[0]["offs"]))
+    g = torch.Generator().manual_seed(4)
+    for it in range(12):
+        versions = [p._version for p in mb.parameters()]
+        for pa, pb in zip(ma.parameters(), mb.parameters()):
+            if it == 7 and pa.dim() == 2:            # a parameter without a gradient: skipped by both
+                pa.grad = None; pb.grad = None
+                continue
+            gr = (torch.randn(pa.shape, generator=g) * 10.0 ** float(torch.randint(-5, 1, (1,), generator=g))).to(DEV)
+            pa.grad = gr.clone(); pb.grad = gr.clone()
+        oa.step(); ob.step(); sa.step(); sb.step()
+        for (n_, pa), pb, v0 in zip(ma.named_parameters(), mb.parameters(), versions):
+            tol = 2.5e-7 * max(1.0, float(pa.abs().max())) * (it + 1)
+            assert float((pa - pb).abs().max()) <= tol, (it, n_)
+            if pb.grad is not None:
+                assert pb._version > v0              # the packed-weight / plan caches see the update
+    assert oa.param_groups[0]["lr"] == ob.param_groups[0]["lr"] == pytest.approx(1e-5)

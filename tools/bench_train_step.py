@@ -22,7 +22,7 @@ import torch
 import torch.optim as optim
 
 
-def build_step(dev, B=16, L=24, rank=0, overlap=True, literal=False):
+def build_step(dev, B=16, L=24, rank=0, overlap=True, literal=False, torch_adam=False):
     """Models, optimizers and the iteration of P/mode.py:148-179 on `dev`.  Returns (step, world-independent state dict)."""
     from bench import synthetic_state
     from srmi import losses, parallel
@@ -50,8 +50,10 @@ def build_step(dev, B=16, L=24, rank=0, overlap=True, literal=False):
 
     l2_loss, cross_ent, tv_loss = losses.MSELoss(), losses.BCELoss(), losses.TVLoss()
     VGG_loss = losses.perceptual_loss(vgg_net)
-    g_optim = optim.Adam(generator.parameters(), lr=1e-4)
-    d_optim = optim.Adam(discriminator.parameters(), lr=1e-4)
+    from srmi import optim as srmi_optim
+    Adam = optim.Adam if torch_adam else srmi_optim.Adam          # srmi.optim.Adam: one launch per model (what mode.train uses)
+    g_optim = Adam(generator.parameters(), lr=1e-4)
+    d_optim = Adam(discriminator.parameters(), lr=1e-4)
     real_label = torch.ones((B, 1), device=dev)
     fake_label = torch.zeros((B, 1), device=dev)
     parallel.broadcast_parameters(generator)
@@ -101,10 +103,11 @@ def build_step(dev, B=16, L=24, rank=0, overlap=True, literal=False):
 MIN_STEP_TFLOP = 0.68      # minimal work of one iteration at B=16, LR 24 (3.4e11 MACs)
 
 
-def cfg3(steps=10, warmup=3, B=16, L=24, dev=None, dist=None, rank=0, world=1, overlap=True, host_profile=False, literal=False):
+def cfg3(steps=10, warmup=3, B=16, L=24, dev=None, dist=None, rank=0, world=1, overlap=True, host_profile=False, literal=False,
+         torch_adam=False):
     """Time `steps` SRGAN iterations.  Returns the record dict (rank 0 prints it in main())."""
     dev = dev or torch.device("cuda:0")
-    step = build_step(dev, B, L, rank, overlap, literal)
+    step = build_step(dev, B, L, rank, overlap, literal, torch_adam)
 
     def barrier():
         torch.cuda.synchronize()
@@ -141,6 +144,7 @@ def cfg3(steps=10, warmup=3, B=16, L=24, dev=None, dist=None, rank=0, world=1, o
            "dtype": "f32", "data": "synthetic", "scaling": "weak",
            "config": {"workload": f"SRGAN step P/mode.py:148-179, per GPU LR {B}x3x{L}x{L} -> HR {4*L}, "
                                   f"D patch {4*L}, VGG19-shaped frozen stack, Adam x2",
+                      "optimizer": "torch.optim.Adam (foreach)" if torch_adam else "srmi.optim.Adam (flat buffers, one launch per model)",
                       "gradient_exchange": "overlapped (GradientAverager.sync)" if overlap else "after backward",
                       "iteration": "reference-literal (wasted G backward in the D step and D weight gradients in the G step kept)"
                                    if literal else "as srmi.mode.train: G output detached for the D step, no D weight gradients in "
@@ -160,6 +164,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--lr-size", type=int, default=24)
     ap.add_argument("--no-overlap", action="store_true", help="exchange gradients after backward (average_gradients)")
+    ap.add_argument("--torch-adam", action="store_true", help="torch.optim.Adam instead of srmi.optim.Adam")
     ap.add_argument("--literal", action="store_true", help="the reference's loop body word for word (its wasted backward work kept)")
     ap.add_argument("--host-profile", action="store_true", help="cProfile of the timed steps' enqueue path (main thread) to stderr")
     args = ap.parse_args()
@@ -173,7 +178,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
     torch.cuda.set_device(local)
     dev = torch.device(f"cuda:{local}")
-    rec = cfg3(args.steps, args.warmup, args.batch, args.lr_size, dev, dist, rank, world, not args.no_overlap, args.host_profile, args.literal)
+    rec = cfg3(args.steps, args.warmup, args.batch, args.lr_size, dev, dist, rank, world, not args.no_overlap, args.host_profile, args.literal, args.torch_adam)
     if rank == 0:
         print(json.dumps(rec), flush=True)
     if dist is not None:
