@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define SRMI_VERSION 115 /* 0.1.5: srmi_adam_step takes double hyper-parameters (0.1.4: bn_train_stats counts num_batches_tracked, epilogue_bwd zero-fills the BN-fed bias gradient;
+#define SRMI_VERSION 116 /* 0.1.6: srmi_conv_args.x_copy; 0.1.5: srmi_adam_step takes double hyper-parameters (0.1.4: bn_train_stats counts num_batches_tracked, epilogue_bwd zero-fills the BN-fed bias gradient;
                             srmi_conv2d_kernel_name reports the f32 kernel that runs) */
 
 /* error codes */
@@ -109,6 +109,12 @@ typedef struct srmi_conv_args {
     void* y;               /* output */
     int32_t flags;         /* SRMI_CONV_* bits, 0 = none */
     int32_t reserved;      /* must be 0 */
+    float* x_copy;         /* NULL, or a dense [N, Cin, H, W] f32 NCHW buffer: the launch ALSO writes its input there,
+                              re-laid out and widened from the halo tile it stages in LDS anyway (no extra pass over x:
+                              `feat` of Generator.forward, P/srgan_model.py:34,39, which the first Upsampler conv reads
+                              as NHWC bf16 and the caller gets as NCHW f32).  Served by "c64_bf16" launches with a dense
+                              64-channel bf16 input, W % 4 == 0 and a 16-byte aligned buffer; every other kernel refuses
+                              a non-NULL x_copy with SRMI_EUNSUPPORTED (srmi_layout_convert is the stand-alone pass) */
 } srmi_conv_args;
 
 /* srmi_conv_args.flags */

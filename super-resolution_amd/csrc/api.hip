@@ -181,6 +181,10 @@ static int conv_fwd_one(const srmi_conv_args* a, hipStream_t s, void* ws = nullp
         set_error("conv: PReLU needs alpha");
         return SRMI_EINVAL;
     }
+    if (a->x_copy && select_kernel(a->d) != K_C64_BF16) {
+        set_error("conv: x_copy is served by the c64_bf16 kernel only (this descriptor runs %s)", kernel_label(select_kernel(a->d)));
+        return SRMI_EUNSUPPORTED;
+    }
     switch (select_kernel(a->d)) {
         case K_C64_BF16: return c64_launch(*a, g, s);
         case K_THIN_BF16: return thin_launch(*a, g, s);   // rejects a residual (SRMI_EUNSUPPORTED)
@@ -284,6 +288,7 @@ int srmi_conv2d_fwd_ws(const srmi_conv_args* a, void* ws, size_t ws_bytes, void*
 static int fuse_kind(const srmi_conv_args* a1, const srmi_conv_args* a2) {
     ConvGeom g;
     if (conv_geom(a1->d, &g) || conv_geom(a2->d, &g)) return 0;
+    if (a1->x_copy || a2->x_copy) return 0;          // the fused kernels do not write input copies: two launches
     const bool rb = resblock_supported(a1->d, a2->d);
     const bool uf = !rb && upfuse_supported(a1->d, a2->d);
     if (!rb && !uf) return 0;

@@ -33,6 +33,7 @@ struct C64Params {
     int N, H, W, nchunk, in_cs;
     int tiles_x, tiles_y;
     int dbg;  // ablation switches (SRMI_DBG env, investigation only): 1 skip staging, 2 skip K loop, 4 skip epilogue
+    float* xcopy;   // NULL, or [N, 64, H, W] f32: NCHW copy of the input, written from the staged tile (srmi_conv_args.x_copy)
 };
 
 
@@ -188,6 +189,43 @@ __global__ __launch_bounds__(NW * 64, WGPC) void conv_c64_kernel(C64Params p) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 
+    // ---- optional NCHW f32 copy of the INPUT (srmi_conv_args.x_copy): the tile's interior is in LDS anyway ----
+    // A unit = (4 consecutive pixels of a tile row, 8 channels): four 16-byte LDS reads, eight 16-byte stores (one per
+    // channel plane).  The octet index runs fastest over the lanes: 8 lanes read one pixel's whole 128-byte line (two
+    // pixels of equal parity per 16-lane group: 2-way conflicts at worst) and a store instruction writes whole 128-byte
+    // lines of 8 channel planes.  ~150 instructions per thread, once per workgroup, under the first weight taps' DMA.
+    if (p.xcopy) {
+        constexpr int QPR = TW / 4;
+        constexpr int UNITS = 8 * TH * QPR;
+        const size_t plane = (size_t)p.H * p.W;
+        float* const dstn = p.xcopy + (size_t)n * 64 * plane;
+        for (int u = tid; u < UNITS; u += NTH) {
+            const int oct = u & 7, t = u >> 3;
+            const int r = t / QPR, qd = t - r * QPR;
+            const int gy = y0 + r, gx = x0 + 4 * qd;
+            if (gy < p.H && gx < p.W) {                    // W % 4 == 0 (checked on the host): whole quads
+                u32x4 v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int col = 1 + 4 * qd + j;
+                    const int P = (r + 1) * ROWP + col;
+                    v[j] = *(const u32x4*)(lds + P * 128 + ((oct ^ swz(P, col)) << 4));
+                }
+                float* const d0 = dstn + (size_t)(8 * oct) * plane + (size_t)gy * p.W + gx;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    f32x4 o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const unsigned w = v[j][c >> 1];
+                        o[j] = __builtin_bit_cast(float, (c & 1) ? (w & 0xffff0000u) : (w << 16));
+                    }
+                    *(f32x4*)(d0 + c * plane) = o;
+                }
+            }
+        }
+    }
+
     // loop-invariant LDS byte offsets of this lane's B fragments: [pixel tile][dx], channel half 0
     // (half 1 flips bit 6: chunk index cb = 4 only toggles bit 2 of the swizzled chunk).
     int boff[PT][3];
@@ -342,6 +380,11 @@ int c64_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     p.epi.act = d.act; p.epi.act_param = d.act_param; p.epi.alpha_pc = d.alpha_per_channel;
     p.N = d.N; p.H = d.H; p.W = d.W; p.nchunk = d.Cout / 64; p.in_cs = g.in_cs;
     p.dbg = dbg_flags();
+    p.xcopy = a.x_copy;
+    if (p.xcopy && (g.in_cs != 64 || (d.W & 3) || ((uintptr_t)p.xcopy & 15))) {
+        set_error("c64_bf16: x_copy needs a dense 64-channel input, W %% 4 == 0 and a 16-byte aligned buffer");
+        return SRMI_EUNSUPPORTED;
+    }
     if (p.dbg & 1024) p.epi.H = 0;      // timing experiment: epilogue arithmetic only (every pixel fails the bounds check: no loads, no stores)
     if (d.N == 0 || d.H == 0 || d.W == 0) return SRMI_OK;
     // tile choice (pick_tile3x3): 6 x 96 (9 pixel tiles per wave), 8 x 64 (8 per wave) or 4 x 32 (2 per wave),

@@ -53,6 +53,7 @@ class ConvArgs(C.Structure):
         ("scale", C.c_void_p), ("shift", C.c_void_p), ("alpha", C.c_void_p),
         ("residual", C.c_void_p), ("y", C.c_void_p),
         ("flags", C.c_int32), ("reserved", C.c_int32),
+        ("x_copy", C.c_void_p),
     ]
 
 

@@ -289,3 +289,42 @@ def test_fused_tail_can_be_switched_off(golden_dir):
         assert float((fused - plain).abs().max()) <= 4e-5
     finally:
         engine.set_fuse_tail(True)
+
+
+def test_feat_copy_from_the_upsampler_launch_equals_the_relayout_pass(golden_dir):
+    """bf16 path: `feat` (NCHW f32) is written by the first Upsampler's c64 launch from the tile it stages
+    (srmi_conv_args.x_copy) - bit-identical to the stand-alone re-layout of the NHWC bf16 tensor; a non-c64 launch
+    refuses an x_copy."""
+    import ctypes as C
+    from srmi import engine, functional as Fn, _lib as L
+    g = _load(golden_dir, "gen_b2_2x3x8x8.npz")
+    x = torch.from_numpy(g["x"]).to(DEV)
+    for shape in [(2, 3, 8, 8), (1, 3, 20, 36), (3, 3, 13, 100)]:
+        xin = x if shape == tuple(x.shape) else torch.from_numpy(W.lr_input(shape, seed=5)).to(DEV)
+        gen = _make_gen(g, "bf16")
+        with torch.no_grad():
+            sr_a, feat_a = gen(xin)
+        plan = gen._plans.get(gen, xin.shape[0], xin.shape[2], xin.shape[3], 1)
+        assert plan.feat_idx is not None
+        try:
+            engine._X_COPY = False
+            engine.invalidate(gen)
+            with torch.no_grad():
+                sr_b, feat_b = gen(xin)
+            assert gen._plans.get(gen, xin.shape[0], xin.shape[2], xin.shape[3], 1).feat_idx is None
+        finally:
+            engine._X_COPY = True
+        assert torch.equal(feat_a, feat_b) and torch.equal(sr_a, sr_b)
+    # W % 4 != 0: the plan falls back to the re-layout pass
+    gen = _make_gen(g, "bf16")
+    with torch.no_grad():
+        gen(torch.from_numpy(W.lr_input((1, 3, 9, 10), seed=6)).to(DEV))
+    assert gen._plans.get(gen, 1, 9, 10, 1).feat_idx is None
+    # a kernel that cannot write the copy says so
+    d = Fn.make_desc(1, 8, 8, 64, 3, 3, in_dtype=L.BF16, out_dtype=L.F32, out_layout=L.NCHW, compute=L.COMPUTE_BF16, act=L.ACT_TANH)
+    a = L.ConvArgs()
+    a.d = d
+    buf = torch.zeros(1 << 16, dtype=torch.uint8, device=DEV)
+    for f in ("x", "w", "scale", "shift", "y", "x_copy"):
+        setattr(a, f, buf.data_ptr())
+    assert L.load().srmi_conv2d_fwd(C.byref(a), 0) == -2          # SRMI_EUNSUPPORTED
