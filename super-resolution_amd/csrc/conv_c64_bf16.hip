@@ -22,6 +22,8 @@
 //     6 x 96 tile: 13 fragment reads feed 36 MFMAs per K-step).
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "c64_common.h"
 
 namespace srmi {
@@ -175,15 +177,6 @@ __global__ __launch_bounds__(NW * 64, WGPC) void conv_c64_kernel(C64Params p) {
             if (tid + i * NTH < XR * RB * 8) *(u32x4*)(lds + lb[i]) = vb[i];
     }
 
-    // per-wave pixel tiles: tile index t = wave*PT + k -> (row, 16-col group)
-    int prow[PT], pcol[PT];
-#pragma unroll
-    for (int k = 0; k < PT; ++k) {
-        const int t = min(wave * PT + k, NPT - 1);
-        prow[k] = t / TWT;
-        pcol[k] = (t - prow[k] * TWT) * 16;
-    }
-
     c64_params_store(par, pregs, p.nchunk, tid);
     // input tile written (own ds_writes: lgkmcnt; the staging loads' vmcnt(0) also retired taps 0..2)
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -226,11 +219,26 @@ __global__ __launch_bounds__(NW * 64, WGPC) void conv_c64_kernel(C64Params p) {
         }
     }
 
+    // Pixel tiles per wave.  With two waves per SIMD (w and w + NW/2 share one) the SIMD's MFMA time per K-step is the SUM
+    // of its two waves' tile counts: 36 tiles = 4 x (5 + 4) fill every slot where 8 x 5 left four of 40 recomputing a
+    // neighbour's tile (see conv_resblock_bf16.hip).  Two instantiations behind a wave-uniform branch, same barriers.
+    constexpr bool SPLIT = NW == 8 && NPT <= (NW / 2) * (2 * PT - 1);
+    constexpr int PTB = SPLIT ? PT - 1 : PT;
+    auto body = [&](auto PC, const int tbase) {
+    constexpr int PTc = decltype(PC)::value;
+    // per-wave pixel tiles: tile index t = tbase + k -> (row, 16-col group)
+    int prow[PTc], pcol[PTc];
+#pragma unroll
+    for (int k = 0; k < PTc; ++k) {
+        const int t = min(tbase + k, NPT - 1);
+        prow[k] = t / TWT;
+        pcol[k] = (t - prow[k] * TWT) * 16;
+    }
     // loop-invariant LDS byte offsets of this lane's B fragments: [pixel tile][dx], channel half 0
     // (half 1 flips bit 6: chunk index cb = 4 only toggles bit 2 of the swizzled chunk).
-    int boff[PT][3];
+    int boff[PTc][3];
 #pragma unroll
-    for (int k = 0; k < PT; ++k)
+    for (int k = 0; k < PTc; ++k)
 #pragma unroll
         for (int dx = 0; dx < 3; ++dx) {
             const int col = pcol[k] + pl + dx;
@@ -238,13 +246,13 @@ __global__ __launch_bounds__(NW * 64, WGPC) void conv_c64_kernel(C64Params p) {
             boff[k][dx] = P * 128 + ((q ^ swz(P, col)) << 4);
         }
 #pragma unroll
-    for (int k = 0; k < PT; ++k)
-        if (wave * PT + k >= NPT) prow[k] = 1 << 20;   // padding tile: the epilogue's bounds check drops it
+    for (int k = 0; k < PTc; ++k)
+        if (tbase + k >= NPT) prow[k] = 1 << 20;   // padding tile: the epilogue's bounds check drops it
 
     for (int s = 0; s < p.nchunk; ++s) {
-        f32x4 acc[PT][4];
+        f32x4 acc[PTc][4];
 #pragma unroll
-        for (int k = 0; k < PT; ++k)
+        for (int k = 0; k < PTc; ++k)
 #pragma unroll
             for (int t = 0; t < 4; ++t) acc[k][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -253,13 +261,13 @@ __global__ __launch_bounds__(NW * 64, WGPC) void conv_c64_kernel(C64Params p) {
         // (one wave per SIMD: nothing else hides the ds_read latency).  Weight taps arrive through a
         // 4-slot LDS-DMA ring; the hand-off for tap g+1 (counted vmcnt + barrier) sits in the MIDDLE of
         // tap g so that the first fragments of the next tap can be prefetched like any others.
-        bf16x8 afr[2][4], bfr[2][PT];
+        bf16x8 afr[2][4], bfr[2][PTc];
         {
             const unsigned char* wslot = wring + ((s * 9) % SLOTS) * C64_TAP_BYTES + lane * 16;
 #pragma unroll
             for (int t = 0; t < 4; ++t) afr[0][t] = *(const bf16x8*)(wslot + t * 1024);
 #pragma unroll
-            for (int k = 0; k < PT; ++k) bfr[0][k] = *(const bf16x8*)(lds + boff[k][0]);
+            for (int k = 0; k < PTc; ++k) bfr[0][k] = *(const bf16x8*)(lds + boff[k][0]);
         }
         if (!(p.dbg & 2))
 #pragma unroll
@@ -283,22 +291,29 @@ __global__ __launch_bounds__(NW * 64, WGPC) void conv_c64_kernel(C64Params p) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) afr[(j + 1) & 1][t] = *(const bf16x8*)(wslot + t * 1024);
 #pragma unroll
-                for (int k = 0; k < PT; ++k)
+                for (int k = 0; k < PTc; ++k)
                     bfr[(j + 1) & 1][k] =
                         *(const bf16x8*)(lds + ((boff[k][dxn] ^ (halfn << 6)) + dyn * (ROWP * 128)));
             }
 #pragma unroll
-            for (int k = 0; k < PT; ++k)
+            for (int k = 0; k < PTc; ++k)
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
                     acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[j & 1][t], bfr[j & 1][k], acc[k][t], 0, 0, 0);
             if (j + 1 < 18) {
                 // interleave: one LDS read per ~3 MFMAs (13 reads under 36 MFMAs)
-                sched_interleave<0, 4 + PT, 4 * PT>();
+                sched_interleave<0, 4 + PTc, 4 * PTc>();
             }
         }
 
-        if (!(p.dbg & 4)) c64_epilogue<PT>(acc, par + s * 192, p.epi, s, n, y0, x0, prow, pcol, pl, q);
+        if (!(p.dbg & 4)) c64_epilogue<PTc>(acc, par + s * 192, p.epi, s, n, y0, x0, prow, pcol, pl, q);
+    }
+    };
+    if constexpr (SPLIT) {
+        if (wave < NW / 2) body(std::integral_constant<int, PT>{}, wave * PT);
+        else body(std::integral_constant<int, PTB>{}, (NW / 2) * PT + (wave - NW / 2) * PTB);
+    } else {
+        body(std::integral_constant<int, PT>{}, wave * PT);
     }
 }
 
