@@ -123,7 +123,9 @@ def per_kernel_times(gen, x, reps):
         for gi, (u0, u1) in enumerate(groups):
             for u in range(u0, u1):
                 label, i, cnt = units[u]
-                if cnt == 2:
+                if cnt > 2:         # the chained trunk: one persistent launch of cnt / 2 ResBlocks
+                    L.check(lib.srmi_conv2d_fwd_seq(C.byref(plan.args[i]), cnt, st))
+                elif cnt == 2:
                     L.check(lib.srmi_conv2d_fwd_pair(C.byref(plan.args[i]), C.byref(plan.args[i + 1]), st))
                 else:
                     L.check(lib.srmi_conv2d_fwd(C.byref(plan.args[i]), st))
@@ -322,6 +324,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the cfg2..cfg5 legs of the N=1 line")
     ap.add_argument("--workload", default="cfg1", choices=["cfg1", "cfg5"])
+    ap.add_argument("--no-chain", action="store_true",
+                    help="A/B: one launch per ResBlock instead of the chained trunk (srmi.engine.set_fuse_chain(False))")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -365,6 +369,9 @@ def main():
             print(json.dumps(result), flush=True)
         return
 
+    if args.no_chain:
+        from srmi import engine as _engine
+        _engine.set_fuse_chain(False)
     gen, x, sd_cpu, x_cpu = build_generator(dev, args.compute)
 
     def barrier():
@@ -396,10 +403,12 @@ def main():
             plan, units, kms = per_kernel_times(gen, x, reps=max(5, min(20, args.steps)))
         # dominant kernel = resblock_c64_kernel (two fused 64->64 convs; 16 launches = 59 % of the step's FLOPs and
         # ~60 % of its time); the whole 64-channel MFMA family (resblock + conv_c64) is reported beside it.
-        dom = "resblock_bf16" if args.compute == "bf16" else "b3_f32"
-        fam = ("c64_bf16", "resblock_bf16") if args.compute == "bf16" else ("generic_f32", "f32t", "b3_f32", "b3h_f32")
+        chained = any(label == "resblock_chain_bf16" for (label, i, cnt) in units)
+        dom = ("resblock_chain_bf16" if chained else "resblock_bf16") if args.compute == "bf16" else "b3_f32"
+        dom_kernel = "resblock_chain_kernel" if chained else "resblock_c64_kernel"
+        fam = ("c64_bf16", "resblock_bf16", "resblock_chain_bf16") if args.compute == "bf16" else ("generic_f32", "f32t", "b3_f32", "b3h_f32")
         peak = PEAK_BF16_TFLOPS if args.compute == "bf16" else PEAK_F32_MFMA_TFLOPS
-        per_layer, flops, t_dom, n_dom, f_fam, t_fam = {}, 0.0, 0.0, 0, 0.0, 0.0
+        per_layer, flops, t_dom, n_dom, f_fam, t_fam, n_blocks = {}, 0.0, 0.0, 0, 0.0, 0.0, 0
         for u, (label, i, cnt) in enumerate(units):
             d = plan.args[i].d
             fl = sum(conv_flops(plan.args[i + c].d) for c in range(cnt))
@@ -407,7 +416,7 @@ def main():
             e = per_layer.setdefault(key, [0, 0.0, 0.0])
             e[0] += 1; e[1] += kms[u]; e[2] += fl
             if label == dom:
-                flops += fl; t_dom += kms[u] * 1e-3; n_dom += 1
+                flops += fl; t_dom += kms[u] * 1e-3; n_dom += 1; n_blocks += cnt // 2
             if label in fam:
                 f_fam += fl; t_fam += kms[u] * 1e-3
         achieved = flops / t_dom / 1e12
@@ -417,7 +426,7 @@ def main():
         try:
             import csv
             for r in csv.DictReader(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_bench_kernel_stats.csv"))):
-                if "resblock_c64_kernel" in r["Name"] and args.compute == "bf16":
+                if dom_kernel in r["Name"] and args.compute == "bf16":
                     trace_us = round(float(r["AverageNs"]) / 1e3, 2)
                     break
         except Exception:
@@ -425,20 +434,25 @@ def main():
         traffic = None       # HBM bytes per launch from the committed rocprofv3 --pmc passes (tools/pmc_summary.py)
         try:
             pm = json.load(open(os.path.join(ROOT, "profiles", PROFILE_TAG + "_pmc_traffic.json")))["kernels"]
-            traffic = next(v["hbm_bytes"] for k, v in pm.items() if "resblock_c64_kernel" in k) if args.compute == "bf16" else None
+            traffic = next(v["hbm_bytes"] for k, v in pm.items() if dom_kernel in k) if args.compute == "bf16" else None
         except Exception:
             traffic = None
-        roofline = {"bound": "mfma", "kernel": "resblock_c64_kernel" if args.compute == "bf16" else "conv_generic_kernel",
-                    "launches_per_step": n_dom, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+        roofline = {"bound": "mfma", "kernel": dom_kernel if args.compute == "bf16" else "conv_generic_kernel",
+                    "launches_per_step": n_dom, "resblocks_per_launch": (n_blocks // n_dom) if args.compute == "bf16" else None,
+                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_source": f"profiles/{PROFILE_TAG}_pmc_traffic.json: committed rocprofv3 --pmc passes of this command "
                                       "(FETCH_SIZE x2 + WRITE_SIZE per launch); NOT measured in this run (PMC needs the profiler)",
                     "avg_launch_us": round(t_dom / n_dom * 1e6, 2),
+                    "avg_resblock_us": round(t_dom / n_blocks * 1e6, 2) if n_blocks else None,
                     # average kernel duration in the committed rocprofv3 kernel trace of this command (kernels of consecutive
                     # launches overlap by ~2 us there: the next one's waves start while the previous one's stores drain)
                     "kernel_trace_avg_us_from_committed_profile": trace_us,
                     "frac_by_committed_kernel_trace": round(flops / n_dom / (trace_us * 1e-6) / 1e12 / peak, 4) if trace_us else None,
                     "flops_per_launch": flops / n_dom,
+                    # compulsory HBM bytes of one launch: its input and its output tensor (16 x 96 x 96 x 64 bf16 each) - for
+                    # the chained trunk that is the whole chain's input and last output (what the blocks hand each other
+                    # between is traffic the chain could keep on chip: the PMC figure shows how much of it still goes out)
                     "algorithmic_bytes_per_launch": 2 * BATCH * LR_H * LR_W * 64 * 2,
                     "mfma_family_tflops": round(f_fam / t_fam / 1e12, 2),
                     "whole_step_frac": round(value / world * 1e6 * FLOP_PER_OUT_PIXEL / 1e12 / peak, 4),

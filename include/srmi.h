@@ -10,7 +10,8 @@
  *
  * Conventions
  *   - plain C, no torch types; every buffer is caller-owned DEVICE memory; the library
- *     allocates nothing and frees nothing, keeps no global state except read-only tables;
+ *     allocates nothing and frees nothing, keeps no global state except read-only tables
+ *     (ONE exception, opt-in per conv: SRMI_CONV_FUSE_CHAIN, which see);
  *   - all work is enqueued on the caller's stream (a hipStream_t passed as void*; NULL = the
  *     null stream); no host synchronisation, no default-stream use => graph-capturable;
  *   - every function returns 0 on success or a negative SRMI_E* code; the message for the
@@ -27,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SRMI_VERSION 116 /* 0.1.6: srmi_conv_args.x_copy; 0.1.5: srmi_adam_step takes double hyper-parameters (0.1.4: bn_train_stats counts num_batches_tracked, epilogue_bwd zero-fills the BN-fed bias gradient;
+#define SRMI_VERSION 117 /* 0.1.7: SRMI_CONV_FUSE_CHAIN + srmi_chain_status + SRMI_ETIMEOUT; 0.1.6: srmi_conv_args.x_copy; 0.1.5: srmi_adam_step takes double hyper-parameters (0.1.4: bn_train_stats counts num_batches_tracked, epilogue_bwd zero-fills the BN-fed bias gradient;
                             srmi_conv2d_kernel_name reports the f32 kernel that runs) */
 
 /* error codes */
@@ -35,6 +36,7 @@ extern "C" {
 #define SRMI_EINVAL (-1)      /* bad descriptor / shape / dtype / alignment */
 #define SRMI_EUNSUPPORTED (-2) /* valid request that no kernel in this build serves */
 #define SRMI_EHIP (-3)        /* HIP runtime error at launch (message has hipGetErrorString) */
+#define SRMI_ETIMEOUT (-4)    /* a persistent (SRMI_CONV_FUSE_CHAIN) launch on this device gave up waiting: see srmi_chain_status */
 
 /* storage dtypes */
 #define SRMI_F32 0
@@ -123,6 +125,22 @@ typedef struct srmi_conv_args {
                                  that never writes y (the ResBlock conv-BN-act-conv-BN-add, P/ops.py:45-48).
                                  y must still be a valid scratch buffer: shapes no fused kernel serves
                                  run as two launches. */
+#define SRMI_CONV_FUSE_CHAIN 2 /* with SRMI_CONV_FUSE_NEXT on the first conv of a fusable ResBlock pair whose residual is its
+                                 own input: consecutive such pairs of one srmi_conv2d_fwd_seq call, each reading the
+                                 previous one's output, may run as ONE persistent launch ("resblock_chain_kernel": every
+                                 workgroup keeps its tile in LDS from block to block and exchanges the two-pixel halo with
+                                 its neighbours through flags in device memory; the 16-block trunk of Generator.forward,
+                                 P/srgan_model.py:32-33).  Results are bit-identical to the launch-per-block form, and every
+                                 block's y is still written in full.  Taken only when every workgroup of the chain is
+                                 resident at once (N * ceil(H/12) * ceil(W/48) <= the device's CU count, W > 64, H >= 12,
+                                 >= 2 blocks); otherwise the pairs run one launch each.  What the flag opts into: (1) the
+                                 library allocates 4 KiB of device memory and a 64-byte host-mapped status word per device
+                                 at the first such launch (never freed) - make that first call outside a graph capture;
+                                 (2) a chained launch on another stream than the previous one first waits on the host for
+                                 that stream (two persistent grids at once would starve each other); (3) residency is a
+                                 property of the whole GPU: if another PROCESS holds CUs for long, a workgroup gives up
+                                 after ~50 ms of waiting, the launch still ends, its outputs are invalid, and every later
+                                 chained launch and srmi_chain_status() on that device return SRMI_ETIMEOUT. */
 
 /* library version (SRMI_VERSION of the build). */
 int srmi_version(void);
@@ -189,6 +207,16 @@ int srmi_conv2d_fwd_seq(const srmi_conv_args* a, int32_t n, void* stream);
  * pair is not a fusable shape (3x3, 64->64->64, NHWC bf16, SRMI_COMPUTE_BF16). Replaces `ResBlock.forward`
  * (P/ops.py:45-48). */
 int srmi_resblock_fwd(const srmi_conv_args* conv1, const srmi_conv_args* conv2, void* stream);
+
+/* SRMI_OK, or SRMI_ETIMEOUT if a SRMI_CONV_FUSE_CHAIN launch on the calling thread's current device has ever given up
+ * waiting for a neighbouring workgroup (sticky; reads a host-mapped word, no synchronisation: call it after the stream
+ * has been synchronised to cover the launches before).  No counterpart in the reference (P/ops.py:45-48 is a Python
+ * loop over modules). */
+int srmi_chain_status(void);
+
+/* Number of convs (2 x blocks, >= 4) that srmi_conv2d_fwd_seq(a, n, .) would run as ONE SRMI_CONV_FUSE_CHAIN launch
+ * starting at a[0]; 0 if a[0] starts no chain (then it goes out as a fused pair or a single conv). */
+int srmi_conv2d_chain_length(const srmi_conv_args* a, int32_t n);
 
 /* Non-zero if srmi_conv2d_fwd_seq would run (conv1 flagged SRMI_CONV_FUSE_NEXT, conv2) as one fused launch:
  * SRMI_FUSE_RESBLOCK (the pair above) or SRMI_FUSE_UPTAIL (below); 0 if they go out as two launches. */

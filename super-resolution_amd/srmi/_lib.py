@@ -58,6 +58,8 @@ class ConvArgs(C.Structure):
 
 
 CONV_FUSE_NEXT = 1
+CONV_FUSE_CHAIN = 2
+ETIMEOUT = -4
 
 
 class EpiDesc(C.Structure):
@@ -90,6 +92,8 @@ SYMBOLS = {
     "srmi_conv2d_fwd_ws": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p, C.c_size_t, C.c_void_p]),
     "srmi_conv2d_fwd_seq": (C.c_int, [C.POINTER(ConvArgs), C.c_int32, C.c_void_p]),
     "srmi_conv2d_can_fuse": (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs)]),
+    "srmi_conv2d_chain_length": (C.c_int, [C.POINTER(ConvArgs), C.c_int32]),
+    "srmi_chain_status": (C.c_int, []),
     "srmi_conv2d_fwd_pair": (C.c_int, [C.POINTER(ConvArgs), C.POINTER(ConvArgs), C.c_void_p]),
     "srmi_srcnn_layer_c1in": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),
     "srmi_srcnn_layer_c1out": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p]),

@@ -82,7 +82,8 @@ class _Seq:
 
     def add(self, block_or_parts, x, y, N, H, W, *, residual=None, shuffle=1, in_layout=L.NHWC, out_layout=L.NHWC,
             in_dtype=None, out_dtype=None, weight=None, k=None, stride=None, cin=None, cout=None, fuse_next=False,
-            shuffle_order=L.SHUFFLE_CRD, in_cstride=0, out_cstride=0, out_coffset=0, res_cstride=0, out_scale=None):
+            shuffle_order=L.SHUFFLE_CRD, in_cstride=0, out_cstride=0, out_coffset=0, res_cstride=0, out_scale=None,
+            chain=False):
         c2d, bn, act = block_or_parts if isinstance(block_or_parts, tuple) else conv_parts(block_or_parts)
         if bn is not None and bn.training:
             raise NotImplementedError("srmi: train-mode BatchNorm is not part of the inference plan")
@@ -117,16 +118,17 @@ class _Seq:
                 alpha = alpha.contiguous()
                 self.keep.append(alpha)
         self.keep += [wp, scale, shift]
-        self.layers.append((desc, x, wp, scale, shift, alpha, residual, y, fuse_next))
+        self.layers.append((desc, x, wp, scale, shift, alpha, residual, y,
+                            (L.CONV_FUSE_NEXT if fuse_next else 0) | (L.CONV_FUSE_CHAIN if fuse_next and chain and _FUSE_CHAIN else 0)))
         self.kernels.append(L.kernel_name(desc))
         return y
 
     def finish(self):
         n = len(self.layers)
         arr = (L.ConvArgs * n)()
-        for i, (desc, x, wp, scale, shift, alpha, residual, y, fuse_next) in enumerate(self.layers):
+        for i, (desc, x, wp, scale, shift, alpha, residual, y, flags) in enumerate(self.layers):
             Fn.fill_args(arr[i], desc, x if x is not None else 0, wp, scale, shift, alpha, residual, y)
-            arr[i].flags = L.CONV_FUSE_NEXT if fuse_next else 0
+            arr[i].flags = flags
         if not _FUSE_TAIL:
             # the fused tail clamps each tap contribution of the last conv to +-900 (int32 fixed-point accumulation,
             # include/srmi.h SRMI_FUSE_UPTAIL): a net whose last conv is not range-bounded runs the pair as two launches
@@ -143,6 +145,12 @@ class _Seq:
         out, i = [], 0
         while i < n:
             kind = 0
+            if arr[i].flags & L.CONV_FUSE_CHAIN:
+                cnt = lib.srmi_conv2d_chain_length(C.byref(arr[i]), n - i)
+                if cnt:
+                    out.append(("resblock_chain_bf16", i, cnt))
+                    i += cnt
+                    continue
             if (arr[i].flags & L.CONV_FUSE_NEXT) and i + 1 < n:
                 kind = lib.srmi_conv2d_can_fuse(C.byref(arr[i]), C.byref(arr[i + 1]))
             if kind:
@@ -155,6 +163,7 @@ class _Seq:
 
 
 _FUSE_TAIL = True
+_FUSE_CHAIN = True
 _X_COPY = os.environ.get("SRMI_FEAT_RELAYOUT", "0") in ("", "0")   # (tests / A-B: False = `feat` always through the stand-alone re-layout pass)
 
 
@@ -164,6 +173,15 @@ def set_fuse_tail(enabled: bool):
     Plans already cached keep their form: call srmi.engine.invalidate(module) to rebuild them."""
     global _FUSE_TAIL
     _FUSE_TAIL = bool(enabled)
+
+
+def set_fuse_chain(enabled: bool):
+    """False: plans built from now on run every ResBlock as its own launch instead of chaining the trunk into one
+    persistent launch (SRMI_CONV_FUSE_CHAIN, include/srmi.h: bit-identical results; the chain needs the whole GPU - every
+    workgroup resident at once - and allocates 4 KiB per device at its first launch).  Plans already cached keep their
+    form: call srmi.engine.invalidate(module) to rebuild them."""
+    global _FUSE_CHAIN
+    _FUSE_CHAIN = bool(enabled)
 
 
 class GeneratorPlan:
@@ -185,7 +203,7 @@ class GeneratorPlan:
             # the pair may run as ONE fused launch (tmp never written); ping-pong outputs because the
             # fused kernel's neighbours read the input's halo while this tile's output is stored
             out = ping[i & 1]
-            s.add(blk.body[0], cur, tmp, N, H, W, fuse_next=True)
+            s.add(blk.body[0], cur, tmp, N, H, W, fuse_next=True, chain=True)
             s.add(blk.body[1], tmp, out, N, H, W, residual=cur)
             cur = out
         feat = s.buf(N, H, W, nf)

@@ -1,0 +1,137 @@
+"""The chained trunk (SRMI_CONV_FUSE_CHAIN: consecutive fused ResBlocks as ONE persistent launch whose workgroups keep
+their tile in LDS and exchange halos through flags, csrc/conv_chain_bf16.hip) against the launch-per-block form of the
+same sequence: bit-identical, every block's output included."""
+import ctypes as C
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+L = importlib.import_module("super-resolution_amd.srmi._lib")
+Fn = importlib.import_module("super-resolution_amd.srmi.functional")
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _build(N, H, W, nblk, seed, alphas=None, act2=None):
+    g = np.random.default_rng(seed)
+    x = torch.from_numpy(g.uniform(-1, 1, (N, H, W, 64)).astype(np.float32)).bfloat16().to(DEV)
+    keep = [x]
+    bufs = [torch.full((N, H, W, 64), 7.0, dtype=torch.bfloat16, device=DEV) for _ in range(nblk)]   # one output per block
+    tmp = torch.full((N, H, W, 64), 3.0, dtype=torch.bfloat16, device=DEV)
+    arr = (L.ConvArgs * (2 * nblk))()
+    cur = x
+    for b in range(nblk):
+        a = 0.25 if alphas is None else alphas[b % len(alphas)]
+        d1 = Fn.make_desc(N, H, W, 64, 64, 3, in_dtype=L.BF16, out_dtype=L.BF16, res_dtype=L.BF16, compute=L.COMPUTE_BF16,
+                          act=L.ACT_PRELU)
+        d2 = Fn.make_desc(N, H, W, 64, 64, 3, in_dtype=L.BF16, out_dtype=L.BF16, res_dtype=L.BF16, compute=L.COMPUTE_BF16,
+                          act=L.ACT_NONE if act2 is None else act2, act_param=0.1)
+        ws = [torch.from_numpy((g.standard_normal((64, 64, 3, 3)) / 30.0).astype(np.float32)).to(DEV) for _ in range(2)]
+        wp = [Fn.pack_weights(d1, ws[0]), Fn.pack_weights(d2, ws[1])]
+        sc = [torch.from_numpy(g.uniform(0.5, 1.2, 64).astype(np.float32)).to(DEV) for _ in range(2)]
+        sh = [torch.from_numpy(g.uniform(-0.2, 0.2, 64).astype(np.float32)).to(DEV) for _ in range(2)]
+        al = torch.tensor([a], dtype=torch.float32, device=DEV)
+        keep += wp + sc + sh + [al]
+        Fn.fill_args(arr[2 * b], d1, cur, wp[0], sc[0], sh[0], al, None, tmp)
+        Fn.fill_args(arr[2 * b + 1], d2, tmp, wp[1], sc[1], sh[1], None, cur, bufs[b])
+        cur = bufs[b]
+    return arr, bufs, tmp, keep
+
+
+def _run(arr, n, flags):
+    for i in range(0, n, 2):
+        arr[i].flags = flags
+    L.check(L.load().srmi_conv2d_fwd_seq(arr, n, Fn.stream_ptr()))
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("case", [
+    dict(N=16, H=96, W=96, nblk=16),                  # cfg1's trunk: 256 workgroups, one per CU
+    dict(N=1, H=96, W=96, nblk=3),
+    dict(N=2, H=50, W=70, nblk=4),                    # ragged tiles both ways
+    dict(N=3, H=12, W=65, nblk=2),                    # one tile row, second tile column one pixel wide + its halo
+    dict(N=1, H=13, W=100, nblk=5, alphas=[0.25, -0.3, 1.0, 0.0]),   # one-pixel second tile row; compare + select slopes
+    dict(N=4, H=60, W=144, nblk=6, act2=L.ACT_LRELU),                # 60 workgroups; an activation on the second conv
+    dict(N=1, H=180, W=192, nblk=24),                 # 60 workgroups, the longest chain of one launch
+])
+def test_chain_equals_launch_per_block(case):
+    lib = L.load()
+    N, H, W, nblk = case["N"], case["H"], case["W"], case["nblk"]
+    arr, bufs, tmp, keep = _build(N, H, W, nblk, seed=5, alphas=case.get("alphas"), act2=case.get("act2"))
+    n = 2 * nblk
+    for i in range(0, n, 2):
+        arr[i].flags = L.CONV_FUSE_NEXT | L.CONV_FUSE_CHAIN
+    assert lib.srmi_conv2d_chain_length(arr, n) == n
+    _run(arr, n, L.CONV_FUSE_NEXT)                    # one launch per block
+    ref = [b.clone() for b in bufs]
+    for b in bufs:
+        b.fill_(-9.0)
+    _run(arr, n, L.CONV_FUSE_NEXT | L.CONV_FUSE_CHAIN)
+    assert lib.srmi_chain_status() == 0, lib.srmi_last_error()
+    assert torch.all(tmp == 3.0)                      # the intermediates are never materialised
+    for i, (r, b) in enumerate(zip(ref, bufs)):
+        assert torch.equal(r, b), "block %d: %d values differ" % (i, int((r != b).sum()))
+    # a second run right behind the first (flags re-zeroed on the stream), outputs poisoned in between
+    for b in bufs:
+        b.fill_(4.0)
+    _run(arr, n, L.CONV_FUSE_NEXT | L.CONV_FUSE_CHAIN)
+    assert torch.equal(ref[-1], bufs[-1]) and torch.equal(ref[0], bufs[0])
+    assert lib.srmi_chain_status() == 0
+
+
+def test_chain_refused_shapes_fall_back():
+    """More workgroups than CUs, narrow images, a foreign residual: no chain, same results through single launches."""
+    lib = L.load()
+    arr, bufs, tmp, keep = _build(8, 96, 200, 3, seed=9)      # 8 * 8 * 5 = 320 workgroups
+    for i in range(0, 6, 2):
+        arr[i].flags = L.CONV_FUSE_NEXT | L.CONV_FUSE_CHAIN
+    assert lib.srmi_conv2d_chain_length(arr, 6) == 0
+    arr, bufs, tmp, keep = _build(2, 40, 64, 3, seed=9)       # W <= 64: the small-tile kernel's shapes
+    for i in range(0, 6, 2):
+        arr[i].flags = L.CONV_FUSE_NEXT | L.CONV_FUSE_CHAIN
+    assert lib.srmi_conv2d_chain_length(arr, 6) == 0
+    _run(arr, 6, L.CONV_FUSE_NEXT | L.CONV_FUSE_CHAIN)
+    got = bufs[-1].clone()
+    _run(arr, 6, L.CONV_FUSE_NEXT)
+    assert torch.equal(got, bufs[-1])
+    # chain of two out of three: the middle block's residual is another tensor
+    arr, bufs, tmp, keep = _build(1, 48, 96, 4, seed=10)
+    other = torch.zeros_like(bufs[0])
+    arr[3].residual = other.data_ptr()
+    for i in range(0, 8, 2):
+        arr[i].flags = L.CONV_FUSE_NEXT | L.CONV_FUSE_CHAIN
+    assert lib.srmi_conv2d_chain_length(arr, 8) == 0          # block 0 alone is no chain
+    assert lib.srmi_conv2d_chain_length(C.byref(arr[4]), 4) == 4
+    _run(arr, 8, L.CONV_FUSE_NEXT | L.CONV_FUSE_CHAIN)
+    got = [b.clone() for b in bufs]
+    _run(arr, 8, L.CONV_FUSE_NEXT)
+    for r, b in zip(got, bufs):
+        assert torch.equal(r, b)
+
+
+def test_generator_chain_switch():
+    """`srmi.engine.set_fuse_chain(False)` gives the launch-per-block plan; both forms return the same bits."""
+    srmi = importlib.import_module("super-resolution_amd.srmi")
+    from importlib import import_module
+    engine = import_module("super-resolution_amd.srmi.engine")
+    torch.manual_seed(3)
+    gen = srmi.Generator(img_feat=3, n_feats=64, kernel_size=3, num_block=5, scale=4).to(DEV).eval().set_compute("bf16")
+    x = torch.rand(2, 3, 48, 96, device=DEV)
+    with torch.no_grad():
+        sr1, f1 = gen(x)
+        plan = gen._plans.get(gen, 2, 48, 96, 1)
+        assert any(lbl == "resblock_chain_bf16" and cnt == 10 for (lbl, i0, cnt) in plan.launches), plan.launches
+        engine.set_fuse_chain(False)
+        try:
+            engine.invalidate(gen)
+            sr2, f2 = gen(x)
+            plan2 = gen._plans.get(gen, 2, 48, 96, 1)
+            assert not any(lbl == "resblock_chain_bf16" for (lbl, i0, cnt) in plan2.launches)
+        finally:
+            engine.set_fuse_chain(True)
+            engine.invalidate(gen)
+    torch.cuda.synchronize()
+    assert torch.equal(sr1, sr2) and torch.equal(f1, f2)
+    assert L.load().srmi_chain_status() == 0
