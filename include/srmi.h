@@ -141,6 +141,12 @@ typedef struct srmi_conv_args {
                                  property of the whole GPU: if another PROCESS holds CUs for long, a workgroup gives up
                                  after ~50 ms of waiting, the launch still ends, its outputs are invalid, and every later
                                  chained launch and srmi_chain_status() on that device return SRMI_ETIMEOUT. */
+#define SRMI_CONV_Y_TRANSIENT 4 /* with SRMI_CONV_FUSE_CHAIN on the first conv of a pair: the pair's output y (conv2->y) is read
+                                 ONLY by the next pair of the sequence, so when both run inside one chained launch y need
+                                 not be written in full: the launch stores just the two outermost pixel rows and columns of
+                                 every 12 x 48 tile (what the neighbouring tiles' halos read) - 38 % of the bytes - and the
+                                 rest of y keeps whatever it held.  The last block of a chained launch, and every pair that
+                                 runs as its own launch, always writes y in full. */
 
 /* library version (SRMI_VERSION of the build). */
 int srmi_version(void);

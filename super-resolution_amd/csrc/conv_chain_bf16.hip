@@ -23,7 +23,7 @@
 namespace srmi {
 
 constexpr int CHAIN_MAX_BLOCKS = 24;
-constexpr unsigned CHAIN_SPIN_LIMIT = 1u << 15;   // polls of ~1 us (load round trip + s_sleep) before a workgroup gives up
+constexpr unsigned CHAIN_SPIN_LIMIT = 1u << 19;   // polls of ~1-2 us (load round trip + s_sleep) before a workgroup gives up: ~1 s
 
 struct ChainBlk {      // what changes from block to block
     const bf16_t* w1; const bf16_t* w2;
@@ -32,6 +32,8 @@ struct ChainBlk {      // what changes from block to block
     bf16_t* y;
     int act1; float act_param1; int alpha_pc1;
     int act2; float act_param2; int alpha_pc2;
+    int halo_only;      // y is read by the next block of this launch only: store just the two-pixel border of every tile
+    int pad_;
 };
 
 struct ChainParams {
@@ -147,6 +149,7 @@ __global__ __launch_bounds__(512, 1) void resblock_chain_kernel(ChainParams p) {
         c64_params_load(pregs1, e1, 1, tid);
         c64_params_load(pregs2, e2, 1, tid);
         const bf16_t* src = kb == 0 ? p.x : (const bf16_t*)kp->blk[kb - 1].y;
+        const bool halo_only = B.halo_only != 0;
         const __amdgpu_buffer_rsrc_t xres =
             __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)n * p.H * p.W * 64), 0, img_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t yres =
@@ -423,7 +426,11 @@ __global__ __launch_bounds__(512, 1) void resblock_chain_kernel(ChainParams p) {
                         if (!ok) { o0 = (u32x4){0u, 0u, 0u, 0u}; o1 = o0; }     // outside the image: the next conv's zero padding
                         *(u32x4*)(lds + ra[k]) = o0;
                         *(u32x4*)(lds + (ra[k] ^ 64)) = o1;
-                        const unsigned off = ok ? (unsigned)oy * row_bytes + (unsigned)ox * 128u + 16u * q : OOB;   // (out of range: dropped)
+                        // (an intermediate block of a chain whose y nobody else reads publishes only what the neighbours' halo
+                        //  rings take: the two outermost pixel rows and columns of the tile)
+                        const int oxl = pcol[k] + pl + opq;
+                        const bool wanted = !halo_only || prow[k] < 2 || prow[k] >= TH - 2 || oxl < 2 || oxl >= TW - 2;
+                        const unsigned off = ok && wanted ? (unsigned)oy * row_bytes + (unsigned)ox * 128u + 16u * q : OOB;   // (out of range: dropped)
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_t, o0), yres, off, 0, SC1);
                         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_t, o1), yres, off + 64, 0, SC1);
                     }
@@ -564,6 +571,7 @@ int chain_launch(const srmi_conv_args* a, int L, hipStream_t s) {
         B.y = (bf16_t*)a2.y;
         B.act1 = a1.d.act; B.act_param1 = a1.d.act_param; B.alpha_pc1 = a1.d.alpha_per_channel;
         B.act2 = a2.d.act; B.act_param2 = a2.d.act_param; B.alpha_pc2 = a2.d.alpha_per_channel;
+        B.halo_only = (i + 1 < L) && (a1.flags & SRMI_CONV_Y_TRANSIENT) ? 1 : 0;
     }
     const unsigned nb = (unsigned)(p.N * p.tiles_x * p.tiles_y);
     // two persistent grids at once would each hold half the CUs and wait for the other half: a chain launch on another

@@ -59,6 +59,7 @@ class ConvArgs(C.Structure):
 
 CONV_FUSE_NEXT = 1
 CONV_FUSE_CHAIN = 2
+CONV_Y_TRANSIENT = 4
 ETIMEOUT = -4
 
 

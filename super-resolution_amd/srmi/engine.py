@@ -83,7 +83,7 @@ class _Seq:
     def add(self, block_or_parts, x, y, N, H, W, *, residual=None, shuffle=1, in_layout=L.NHWC, out_layout=L.NHWC,
             in_dtype=None, out_dtype=None, weight=None, k=None, stride=None, cin=None, cout=None, fuse_next=False,
             shuffle_order=L.SHUFFLE_CRD, in_cstride=0, out_cstride=0, out_coffset=0, res_cstride=0, out_scale=None,
-            chain=False):
+            chain=False, y_transient=False):
         c2d, bn, act = block_or_parts if isinstance(block_or_parts, tuple) else conv_parts(block_or_parts)
         if bn is not None and bn.training:
             raise NotImplementedError("srmi: train-mode BatchNorm is not part of the inference plan")
@@ -119,7 +119,8 @@ class _Seq:
                 self.keep.append(alpha)
         self.keep += [wp, scale, shift]
         self.layers.append((desc, x, wp, scale, shift, alpha, residual, y,
-                            (L.CONV_FUSE_NEXT if fuse_next else 0) | (L.CONV_FUSE_CHAIN if fuse_next and chain and _FUSE_CHAIN else 0)))
+                            (L.CONV_FUSE_NEXT if fuse_next else 0) | (L.CONV_FUSE_CHAIN if fuse_next and chain and _FUSE_CHAIN else 0)
+                            | (L.CONV_Y_TRANSIENT if fuse_next and chain and y_transient and _FUSE_CHAIN else 0)))
         self.kernels.append(L.kernel_name(desc))
         return y
 
@@ -203,7 +204,9 @@ class GeneratorPlan:
             # the pair may run as ONE fused launch (tmp never written); ping-pong outputs because the
             # fused kernel's neighbours read the input's halo while this tile's output is stored
             out = ping[i & 1]
-            s.add(blk.body[0], cur, tmp, N, H, W, fuse_next=True, chain=True)
+            # (the output of every block but the last is read by the next block only: inside a chained launch just its
+            #  halo strips reach memory)
+            s.add(blk.body[0], cur, tmp, N, H, W, fuse_next=True, chain=True, y_transient=(i + 1 < len(gen.body)))
             s.add(blk.body[1], tmp, out, N, H, W, residual=cur)
             cur = out
         feat = s.buf(N, H, W, nf)

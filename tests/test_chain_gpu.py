@@ -79,6 +79,18 @@ def test_chain_equals_launch_per_block(case):
     _run(arr, n, L.CONV_FUSE_NEXT | L.CONV_FUSE_CHAIN)
     assert torch.equal(ref[-1], bufs[-1]) and torch.equal(ref[0], bufs[0])
     assert lib.srmi_chain_status() == 0
+    # SRMI_CONV_Y_TRANSIENT: intermediate outputs reach memory only as the two-pixel border of every 12 x 48 tile
+    for b in bufs:
+        b.fill_(4.0)
+    _run(arr, n, L.CONV_FUSE_NEXT | L.CONV_FUSE_CHAIN | L.CONV_Y_TRANSIENT)
+    assert lib.srmi_chain_status() == 0
+    assert torch.equal(ref[-1], bufs[-1])             # the chain's result: written in full
+    yy = torch.arange(H, device=DEV) % 12
+    xx = torch.arange(W, device=DEV) % 48
+    border = ((yy < 2) | (yy >= 10))[:, None] | ((xx < 2) | (xx >= 46))[None, :]
+    for r, b in zip(ref[:-1], bufs[:-1]):
+        assert torch.equal(r[:, border], b[:, border])
+        assert torch.all(b[:, ~border] == 4.0)
 
 
 def test_chain_refused_shapes_fall_back():
