@@ -416,7 +416,7 @@ def main():
             e = per_layer.setdefault(key, [0, 0.0, 0.0])
             e[0] += 1; e[1] += kms[u]; e[2] += fl
             if label == dom:
-                flops += fl; t_dom += kms[u] * 1e-3; n_dom += 1; n_blocks += cnt // 2
+                flops += fl; t_dom += kms[u] * 1e-3; n_dom += 1; n_blocks += cnt / 2     # (a chain's tail conv: half a block)
             if label in fam:
                 f_fam += fl; t_fam += kms[u] * 1e-3
         achieved = flops / t_dom / 1e12
@@ -438,7 +438,7 @@ def main():
         except Exception:
             traffic = None
         roofline = {"bound": "mfma", "kernel": dom_kernel if args.compute == "bf16" else "conv_generic_kernel",
-                    "launches_per_step": n_dom, "resblocks_per_launch": (n_blocks // n_dom) if args.compute == "bf16" else None,
+                    "launches_per_step": n_dom, "resblocks_per_launch": (n_blocks / n_dom) if args.compute == "bf16" else None,
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic,
                     "traffic_source": f"profiles/{PROFILE_TAG}_pmc_traffic.json: committed rocprofv3 --pmc passes of this command "

@@ -33,7 +33,8 @@ struct ChainBlk {      // what changes from block to block
     int act1; float act_param1; int alpha_pc1;
     int act2; float act_param2; int alpha_pc2;
     int halo_only;      // y is read by the next block of this launch only: store just the two-pixel border of every tile
-    int pad_;
+    int single;         // ONE conv (w2, scale2, ...) on the block's input + a residual from global memory: the chain's tail link
+    const bf16_t* res;  // single: the residual tensor (never written in this launch)
 };
 
 struct ChainParams {
@@ -136,8 +137,9 @@ __global__ __launch_bounds__(512, 1) void resblock_chain_kernel(ChainParams p) {
         wb1 = (const unsigned char*)B.w1;
         wb2 = (const unsigned char*)B.w2;
         asm volatile("" : "+s"(wb1), "+s"(wb2));
-        issue_slot(0);          // (every wave is past the previous block's K loops: barrier A below)
-        issue_slot(1);
+        const bool single = B.single != 0;
+        if (single) { issue_slot(9); issue_slot(10); }      // (every wave is past the previous block's K loops: barrier A below)
+        else { issue_slot(0); issue_slot(1); }
         C64Epi e1, e2;
         e1.scale = B.scale1; e1.shift = B.shift1; e1.alpha = B.alpha1; e1.res = nullptr; e1.y = nullptr;
         e1.H = p.H; e1.W = p.W; e1.Cout = 64; e1.out_cs = 64; e1.out_co = 0; e1.mode = C64_PLAIN;
@@ -224,6 +226,10 @@ __global__ __launch_bounds__(512, 1) void resblock_chain_kernel(ChainParams p) {
 
         auto body = [&](auto P1, auto P2, const int t1base, const int t2base) {
             constexpr int PT1c = decltype(P1)::value, PT2c = decltype(P2)::value;
+            bf16x8 afr[2][4];
+            u32x4 rpre[PT2c][2];     // the residual of this wave's output tiles
+            int ra[PT2c];            // LDS byte address of (this lane's pixel of output tile k, chunk q): the output goes back there
+            if (!single) {
             // ================= phase 1: conv1 over the flattened T region =================================
             int boff1[PT1c][3];
             unsigned inside = 0;     // bit k: this lane's pixel of tile k lies inside the image (else T = 0: conv2's zero padding)
@@ -245,7 +251,7 @@ __global__ __launch_bounds__(512, 1) void resblock_chain_kernel(ChainParams p) {
             for (int k = 0; k < PT1c; ++k)
 #pragma unroll
                 for (int t = 0; t < 4; ++t) acc[k][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            bf16x8 afr[2][4], bfr[2][PT1c];
+            bf16x8 bfr[2][PT1c];
 #pragma unroll
             for (int t = 0; t < 4; ++t) afr[0][t] = *(const bf16x8*)(wring + lane * 16 + t * 1024);
 #pragma unroll
@@ -276,8 +282,6 @@ __global__ __launch_bounds__(512, 1) void resblock_chain_kernel(ChainParams p) {
 
             // ---- phase 2: the residual (= centre of the x tile) into registers, then T = act(affine1(acc)) as bf16 over
             // the x tile (zero outside the image) ----
-            u32x4 rpre[PT2c][2];
-            int ra[PT2c];            // LDS byte address of (this lane's pixel of tile k, chunk q): the output goes back there
             {
                 int opr;      // (opaque zero in the address: keeps these loads where they are written)
                 asm volatile("v_mov_b32 %0, 0" : "=v"(opr));
@@ -332,11 +336,34 @@ __global__ __launch_bounds__(512, 1) void resblock_chain_kernel(ChainParams p) {
             else twrite(std::integral_constant<int, 2>{});
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();           // T complete
+            } else {
+                // ---- the tail link: ONE conv on the x tile itself (conv02 of Generator.forward + the long skip add).  Its
+                // weights stream as conv "2"'s; its operand window is the T window moved one pixel row and column into the x
+                // tile; the residual is a tensor in global memory that nobody writes in this launch (plain loads) ----
+#pragma unroll
+                for (int t = 0; t < 4; ++t) afr[0][t] = *(const bf16x8*)(frag(18) + t * 1024);
+                const __amdgpu_buffer_rsrc_t rres =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)(B.res + (size_t)n * p.H * p.W * 64), 0, img_bytes, 0x00020000);
+                int opr;
+                asm volatile("v_mov_b32 %0, 0" : "=v"(opr));
+#pragma unroll
+                for (int k = 0; k < PT2c; ++k) {
+                    const int t = t2base + k;
+                    const int trow = t / TWT, colp = (t - trow * TWT) * 16 + pl + opr;
+                    const int P = (trow + 2) * ROWP + colp + 2;
+                    ra[k] = P * 128 + ((q ^ c64_key(P)) << 4);
+                    const int oy = y0 + trow, ox = x0 + colp;
+                    const unsigned off = (oy < p.H && ox < p.W) ? (unsigned)oy * row_bytes + (unsigned)ox * 128u + 16u * q : OOB;   // (out of range: zeros)
+                    rpre[k][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, off, 0, 0));
+                    rpre[k][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, off + 64, 0, 0));
+                }
+            }
             // ================= phase 3: conv2 from T ==================================================
             int prow[PT2c], pcol[PT2c];
             int boff2[PT2c][3];
             int opaque0;       // keeps this phase's address arithmetic below conv1's K loop (which runs at the register limit)
             asm volatile("v_mov_b32 %0, 0" : "=v"(opaque0));
+            const int shp = single ? ROWP + 1 : 0;      // (the tail link reads x, which lies one pixel row and column further in)
 #pragma unroll
             for (int k = 0; k < PT2c; ++k) {
                 const int t = t2base + k;
@@ -345,7 +372,7 @@ __global__ __launch_bounds__(512, 1) void resblock_chain_kernel(ChainParams p) {
 #pragma unroll
                 for (int dx = 0; dx < 3; ++dx) {
                     const int col = pcol[k] + pl + opaque0 + dx;
-                    const int P = prow[k] * ROWP + col;
+                    const int P = prow[k] * ROWP + col + shp;
                     boff2[k][dx] = P * 128 + ((q ^ c64_key(P)) << 4);
                 }
             }
@@ -517,11 +544,31 @@ static bool chain_link_ok(const srmi_conv_args& a1, const srmi_conv_args& a2) {
     return true;
 }
 
-// number of ResBlock PAIRS starting at a[0] (a[0], a[1]), (a[2], a[3]), ... that can run as one chain; 0 or >= 2.
-// `fusable(a1, a2)` is api.hip's test for the fused ResBlock pair.
-int chain_run_length(const srmi_conv_args* a, int n, bool (*fusable)(const srmi_conv_args*, const srmi_conv_args*)) {
+// a single conv right behind a chain that can run as its tail link: 3x3 64 -> 64 on the last block's output, plus a
+// dense bf16 residual that no block of the chain writes (conv02 + the long skip of Generator.forward, P/srgan_model.py:33-34)
+static bool chain_tail_ok(const srmi_conv_args* a, int L, const srmi_conv_args& t) {
+    const srmi_conv_desc& d = t.d;
+    if (!(t.flags & SRMI_CONV_FUSE_CHAIN) || (t.flags & SRMI_CONV_FUSE_NEXT) || t.x_copy) return false;
+    if (!c64_supported(d) || d.Cout != 64 || d.shuffle != 1) return false;
+    if (d.N != a[0].d.N || d.H != a[0].d.H || d.W != a[0].d.W) return false;
+    if ((d.in_cstride && d.in_cstride != 64) || (d.out_cstride && d.out_cstride != 64) || d.out_coffset) return false;
+    if (d.res_cstride && d.res_cstride != 64) return false;
+    if (!t.x || t.x != a[2 * L - 1].y || !t.w || !t.y || !t.scale || !t.shift) return false;
+    if (!t.residual || d.res_dtype != SRMI_BF16) return false;
+    if (d.act == SRMI_ACT_PRELU && !t.alpha) return false;
+    if (((uintptr_t)t.w | (uintptr_t)t.y | (uintptr_t)t.residual) & 15) return false;
+    if (t.y == t.x || t.y == t.residual) return false;
+    for (int i = 0; i < L; ++i)
+        if (a[2 * i + 1].y == t.residual || a[2 * i + 1].y == t.y) return false;   // (the residual is read by plain loads; y must not be a live halo source)
+    return true;
+}
+
+// Convs of a[0 .. n) that can run as one chain starting at a[0]: L >= 2 ResBlock pairs (a[0], a[1]), (a[2], a[3]), ... and,
+// if one follows, a tail conv (*tail = true): 2 L (+ 1), or 0.  `fusable(a1, a2)` is api.hip's test for the fused ResBlock pair.
+int chain_run_length(const srmi_conv_args* a, int n, bool (*fusable)(const srmi_conv_args*, const srmi_conv_args*), bool* tail) {
+    if (tail) *tail = false;
     int L = 0;
-    while (L < CHAIN_MAX_BLOCKS && 2 * L + 1 < n) {
+    while (L < CHAIN_MAX_BLOCKS - 1 && 2 * L + 1 < n) {
         const srmi_conv_args& a1 = a[2 * L];
         const srmi_conv_args& a2 = a[2 * L + 1];
         if (!(a1.flags & SRMI_CONV_FUSE_NEXT) || !(a1.flags & SRMI_CONV_FUSE_CHAIN)) break;
@@ -536,14 +583,21 @@ int chain_run_length(const srmi_conv_args* a, int n, bool (*fusable)(const srmi_
     if (L < 2) return 0;
     const srmi_conv_desc& d = a[0].d;
     const long long nb = (long long)d.N * ((d.W + 47) / 48) * ((d.H + 11) / 12);
-    std::lock_guard<std::mutex> lk(g_chain_mu);
-    ChainDev* cd = chain_dev();
-    if (!cd) return 0;
-    if (nb > cd->cus || nb * 4 > 4096) return 0;          // every workgroup must be resident at once (one per CU)
-    return L;
+    {
+        std::lock_guard<std::mutex> lk(g_chain_mu);
+        ChainDev* cd = chain_dev();
+        if (!cd) return 0;
+        if (nb > cd->cus || nb * 4 > 4096) return 0;          // every workgroup must be resident at once (one per CU)
+    }
+    const bool t = 2 * L < n && chain_tail_ok(a, L, a[2 * L]);
+    if (tail) *tail = t;
+    return 2 * L + (t ? 1 : 0);
 }
 
-int chain_launch(const srmi_conv_args* a, int L, hipStream_t s) {
+// nconv = what chain_run_length returned for (a, .)
+int chain_launch(const srmi_conv_args* a, int nconv, hipStream_t s) {
+    const int L = nconv / 2;
+    const bool tail = (nconv & 1) != 0;
     const srmi_conv_desc& d = a[0].d;
     if (d.N == 0 || d.H == 0 || d.W == 0) return SRMI_OK;
     std::lock_guard<std::mutex> lk(g_chain_mu);
@@ -560,7 +614,7 @@ int chain_launch(const srmi_conv_args* a, int L, hipStream_t s) {
     p.flags = cd->flags; p.status = cd->status_dev;
     p.N = d.N; p.H = d.H; p.W = d.W;
     p.tiles_x = (d.W + 47) / 48; p.tiles_y = (d.H + 11) / 12;
-    p.nblk = L;
+    p.nblk = L + (tail ? 1 : 0);
     for (int i = 0; i < L; ++i) {
         const srmi_conv_args& a1 = a[2 * i];
         const srmi_conv_args& a2 = a[2 * i + 1];
@@ -571,7 +625,19 @@ int chain_launch(const srmi_conv_args* a, int L, hipStream_t s) {
         B.y = (bf16_t*)a2.y;
         B.act1 = a1.d.act; B.act_param1 = a1.d.act_param; B.alpha_pc1 = a1.d.alpha_per_channel;
         B.act2 = a2.d.act; B.act_param2 = a2.d.act_param; B.alpha_pc2 = a2.d.alpha_per_channel;
-        B.halo_only = (i + 1 < L) && (a1.flags & SRMI_CONV_Y_TRANSIENT) ? 1 : 0;
+        B.halo_only = (i + 1 < L + (tail ? 1 : 0)) && (a1.flags & SRMI_CONV_Y_TRANSIENT) ? 1 : 0;
+    }
+    if (tail) {
+        const srmi_conv_args& t = a[2 * L];
+        ChainBlk& B = p.blk[L];
+        B.single = 1;
+        B.w2 = (const bf16_t*)t.w;
+        B.scale2 = t.scale; B.shift2 = t.shift; B.alpha2 = t.alpha;
+        B.y = (bf16_t*)t.y;
+        B.res = (const bf16_t*)t.residual;
+        B.act2 = t.d.act; B.act_param2 = t.d.act_param; B.alpha_pc2 = t.d.alpha_per_channel;
+        // (conv "1"'s parameters are loaded but never used: point them at valid memory)
+        B.scale1 = t.scale; B.shift1 = t.shift; B.alpha1 = t.alpha; B.act1 = SRMI_ACT_NONE;
     }
     const unsigned nb = (unsigned)(p.N * p.tiles_x * p.tiles_y);
     // two persistent grids at once would each hold half the CUs and wait for the other half: a chain launch on another

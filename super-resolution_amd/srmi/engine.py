@@ -119,7 +119,7 @@ class _Seq:
                 self.keep.append(alpha)
         self.keep += [wp, scale, shift]
         self.layers.append((desc, x, wp, scale, shift, alpha, residual, y,
-                            (L.CONV_FUSE_NEXT if fuse_next else 0) | (L.CONV_FUSE_CHAIN if fuse_next and chain and _FUSE_CHAIN else 0)
+                            (L.CONV_FUSE_NEXT if fuse_next else 0) | (L.CONV_FUSE_CHAIN if chain and _FUSE_CHAIN else 0)
                             | (L.CONV_Y_TRANSIENT if fuse_next and chain and y_transient and _FUSE_CHAIN else 0)))
         self.kernels.append(L.kernel_name(desc))
         return y
@@ -204,13 +204,13 @@ class GeneratorPlan:
             # the pair may run as ONE fused launch (tmp never written); ping-pong outputs because the
             # fused kernel's neighbours read the input's halo while this tile's output is stored
             out = ping[i & 1]
-            # (the output of every block but the last is read by the next block only: inside a chained launch just its
+            # (every block's output is read by the next conv of the sequence only: inside a chained launch just its
             #  halo strips reach memory)
-            s.add(blk.body[0], cur, tmp, N, H, W, fuse_next=True, chain=True, y_transient=(i + 1 < len(gen.body)))
+            s.add(blk.body[0], cur, tmp, N, H, W, fuse_next=True, chain=True, y_transient=True)
             s.add(blk.body[1], tmp, out, N, H, W, residual=cur)
             cur = out
         feat = s.buf(N, H, W, nf)
-        s.add(gen.conv02, cur, feat, N, H, W, residual=skip)      # P/srgan_model.py:33-34
+        s.add(gen.conv02, cur, feat, N, H, W, residual=skip, chain=True)      # P/srgan_model.py:33-34 (the chain's tail link)
         x, h, w = feat, H, W
         for j, up in enumerate(gen.tail):          # Upsampler, P/ops.py:74-78
             r = up.body[1].upscale_factor

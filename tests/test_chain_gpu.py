@@ -54,7 +54,7 @@ def _run(arr, n, flags):
     dict(N=3, H=12, W=65, nblk=2),                    # one tile row, second tile column one pixel wide + its halo
     dict(N=1, H=13, W=100, nblk=5, alphas=[0.25, -0.3, 1.0, 0.0]),   # one-pixel second tile row; compare + select slopes
     dict(N=4, H=60, W=144, nblk=6, act2=L.ACT_LRELU),                # 60 workgroups; an activation on the second conv
-    dict(N=1, H=180, W=192, nblk=24),                 # 60 workgroups, the longest chain of one launch
+    dict(N=1, H=180, W=192, nblk=23),                 # 60 workgroups, the longest chain of one launch
 ])
 def test_chain_equals_launch_per_block(case):
     lib = L.load()
@@ -93,6 +93,54 @@ def test_chain_equals_launch_per_block(case):
         assert torch.all(b[:, ~border] == 4.0)
 
 
+@pytest.mark.parametrize("case", [
+    dict(N=16, H=96, W=96, nblk=16),
+    dict(N=2, H=50, W=70, nblk=2),
+    dict(N=1, H=25, W=130, nblk=3, act=L.ACT_PRELU),
+])
+def test_chain_with_tail_conv(case):
+    """The single conv behind the last block (conv02 + long skip add, P/srgan_model.py:33-34) as the chain's last link."""
+    lib = L.load()
+    N, H, W, nblk = case["N"], case["H"], case["W"], case["nblk"]
+    arr0, bufs, tmp, keep = _build(N, H, W, nblk, seed=21)
+    n = 2 * nblk + 1
+    arr = (L.ConvArgs * n)()
+    for i in range(n - 1):
+        C.memmove(C.byref(arr[i]), C.byref(arr0[i]), C.sizeof(L.ConvArgs))
+    g = np.random.default_rng(4)
+    d = Fn.make_desc(N, H, W, 64, 64, 3, in_dtype=L.BF16, out_dtype=L.BF16, res_dtype=L.BF16, compute=L.COMPUTE_BF16,
+                     act=case.get("act", L.ACT_NONE))
+    w = torch.from_numpy((g.standard_normal((64, 64, 3, 3)) / 30.0).astype(np.float32)).to(DEV)
+    wp = Fn.pack_weights(d, w)
+    sc = torch.from_numpy(g.uniform(0.5, 1.2, 64).astype(np.float32)).to(DEV)
+    sh = torch.from_numpy(g.uniform(-0.2, 0.2, 64).astype(np.float32)).to(DEV)
+    al = torch.tensor([0.3], dtype=torch.float32, device=DEV)
+    x0 = keep[0]
+    out = torch.full((N, H, W, 64), 7.0, dtype=torch.bfloat16, device=DEV)
+    Fn.fill_args(arr[n - 1], d, bufs[-1], wp, sc, sh, al if case.get("act") else None, x0, out)
+
+    def run(chain):
+        for i in range(0, n - 1, 2):
+            arr[i].flags = L.CONV_FUSE_NEXT | ((L.CONV_FUSE_CHAIN | L.CONV_Y_TRANSIENT) if chain else 0)
+        arr[n - 1].flags = L.CONV_FUSE_CHAIN if chain else 0
+        L.check(lib.srmi_conv2d_fwd_seq(arr, n, Fn.stream_ptr()))
+        torch.cuda.synchronize()
+
+    run(False)
+    ref = out.clone()
+    out.fill_(-2.0)
+    for i in range(0, n - 1, 2):
+        arr[i].flags = L.CONV_FUSE_NEXT | L.CONV_FUSE_CHAIN
+    arr[n - 1].flags = L.CONV_FUSE_CHAIN
+    assert lib.srmi_conv2d_chain_length(arr, n) == n
+    run(True)
+    assert lib.srmi_chain_status() == 0
+    assert torch.equal(ref, out), int((ref != out).sum())
+    # a tail whose residual is one of the chain's own outputs stays a launch of its own
+    arr[n - 1].residual = bufs[0].data_ptr()
+    assert lib.srmi_conv2d_chain_length(arr, n) == n - 1
+
+
 def test_chain_refused_shapes_fall_back():
     """More workgroups than CUs, narrow images, a foreign residual: no chain, same results through single launches."""
     lib = L.load()
@@ -107,6 +155,15 @@ def test_chain_refused_shapes_fall_back():
     _run(arr, 6, L.CONV_FUSE_NEXT | L.CONV_FUSE_CHAIN)
     got = bufs[-1].clone()
     _run(arr, 6, L.CONV_FUSE_NEXT)
+    assert torch.equal(got, bufs[-1])
+    # 24 blocks: 23 go out as one chain, the last one as a fused pair of its own
+    arr, bufs, tmp, keep = _build(1, 24, 96, 24, seed=12)
+    for i in range(0, 48, 2):
+        arr[i].flags = L.CONV_FUSE_NEXT | L.CONV_FUSE_CHAIN
+    assert lib.srmi_conv2d_chain_length(arr, 48) == 46
+    _run(arr, 48, L.CONV_FUSE_NEXT | L.CONV_FUSE_CHAIN | L.CONV_Y_TRANSIENT)
+    got = bufs[-1].clone()
+    _run(arr, 48, L.CONV_FUSE_NEXT)
     assert torch.equal(got, bufs[-1])
     # chain of two out of three: the middle block's residual is another tensor
     arr, bufs, tmp, keep = _build(1, 48, 96, 4, seed=10)
@@ -134,7 +191,7 @@ def test_generator_chain_switch():
     with torch.no_grad():
         sr1, f1 = gen(x)
         plan = gen._plans.get(gen, 2, 48, 96, 1)
-        assert any(lbl == "resblock_chain_bf16" and cnt == 10 for (lbl, i0, cnt) in plan.launches), plan.launches
+        assert any(lbl == "resblock_chain_bf16" and cnt == 11 for (lbl, i0, cnt) in plan.launches), plan.launches
         engine.set_fuse_chain(False)
         try:
             engine.invalidate(gen)
