@@ -100,6 +100,9 @@ def per_kernel_times(gen, x, reps):
     plan.args[0].x = x.data_ptr()
     sr = torch.empty(plan.sr_shape, dtype=torch.float32, device=x.device)
     plan.args[n - 1].y = sr.data_ptr()
+    if plan.feat_idx is not None:                # the NCHW f32 copy of `feat` some launch writes on the side (x_copy)
+        feat = torch.empty((plan.N, plan.nf, plan.H, plan.W), dtype=torch.float32, device=x.device)
+        plan.args[plan.feat_idx].x_copy = feat.data_ptr()
     units = plan.launches                       # (label, first conv index, convs in the launch)
     # Runs of identical consecutive launches (the 16 fused ResBlocks) share ONE event pair: recording an event costs the
     # GPU timeline a few microseconds (two events with nothing between them read 5 us apart), which a per-launch pair
@@ -416,7 +419,8 @@ def main():
             e = per_layer.setdefault(key, [0, 0.0, 0.0])
             e[0] += 1; e[1] += kms[u]; e[2] += fl
             if label == dom:
-                flops += fl; t_dom += kms[u] * 1e-3; n_dom += 1; n_blocks += cnt / 2     # (a chain's tail conv: half a block)
+                flops += fl; t_dom += kms[u] * 1e-3; n_dom += 1
+                n_blocks += fl / (2 * conv_flops(plan.args[i].d))     # (a chain's tail convs count by their FLOPs: 0.5 and 2 blocks)
             if label in fam:
                 f_fam += fl; t_fam += kms[u] * 1e-3
         achieved = flops / t_dom / 1e12

@@ -348,9 +348,10 @@ int srmi_conv2d_fwd_seq(const srmi_conv_args* a, int32_t n, void* stream) {
     if (n < 0 || (n > 0 && !a)) { set_error("fwd_seq: bad arguments"); return SRMI_EINVAL; }
     for (int32_t i = 0; i < n; ++i) {
         if ((a[i].flags & SRMI_CONV_FUSE_NEXT) && (a[i].flags & SRMI_CONV_FUSE_CHAIN)) {
-            const int nc = chain_run_length(a + i, n - i, can_fuse_pair);
+            int npairs = 0, kinds[2] = {0, 0};
+            const int nc = chain_run_length(a + i, n - i, can_fuse_pair, &npairs, kinds);
             if (nc >= 4) {
-                int rc = chain_launch(a + i, nc, (hipStream_t)stream);
+                int rc = chain_launch(a + i, npairs, kinds, (hipStream_t)stream);
                 if (rc) return rc;
                 i += nc - 1;
                 continue;

@@ -33,8 +33,11 @@ struct ChainBlk {      // what changes from block to block
     int act1; float act_param1; int alpha_pc1;
     int act2; float act_param2; int alpha_pc2;
     int halo_only;      // y is read by the next block of this launch only: store just the two-pixel border of every tile
-    int single;         // ONE conv (w2, scale2, ...) on the block's input + a residual from global memory: the chain's tail link
-    const bf16_t* res;  // single: the residual tensor (never written in this launch)
+    int single;         // 1: ONE conv (w2, scale2, ...) on the block's input + a residual from global memory (a tail link);
+                        // 2: ONE conv to 64 * nchunk channels with any c64 store mode and plain stores: the chain's LAST link
+    const bf16_t* res;  // single == 1: the residual tensor (never written in this launch)
+    int nchunk, mode;   // single == 2: output chunks of 64 channels, C64_PLAIN / C64_CRD / C64_DCR
+    float* xcopy;       // single == 2: NULL, or the link's input as [N, 64, H, W] f32 (srmi_conv_args.x_copy)
 };
 
 struct ChainParams {
@@ -60,7 +63,8 @@ __global__ __launch_bounds__(512, 1) void resblock_chain_kernel(ChainParams p) {
     constexpr int PT1 = 6, PT1B = 5, PT2 = 5, PT2B = 4;     // tiles per wave: waves 0-3 / waves 4-7 (SIMD partners)
     static_assert(NT1 == (NW / 2) * (PT1 + PT1B) && NPT2 == (NW / 2) * (PT2 + PT2B), "balanced split fills every slot");
     constexpr int SLOT_BYTES = KS * CH_STEP_BYTES, NS = 36 / KS;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[IN_BYTES + SLOTS * SLOT_BYTES + 2 * 768];
+    constexpr int MAXCH = 4;                         // output chunks of the last link
+    __shared__ __attribute__((aligned(16))) unsigned char lds[IN_BYTES + SLOTS * SLOT_BYTES + (1 + MAXCH) * 768];
     unsigned char* const wring = lds + IN_BYTES;
     float* const par = (float*)(lds + IN_BYTES + SLOTS * SLOT_BYTES);
 
@@ -113,12 +117,13 @@ __global__ __launch_bounds__(512, 1) void resblock_chain_kernel(ChainParams p) {
     };
     // hand-off at the top of K-step g when step g+1 opens slot S: slot S landed (own KiB: vmcnt, the others': barrier);
     // slot S-2's fragments were consumed by MFMAs every wave has issued, so slot S+1 is issued into its ring position
-    auto handoff = [&](int g) {
+    // (ns = slots in the block's weight stream: NS, or 9 + 9 per output chunk in the last link)
+    auto handoff = [&](int g, int ns) {
         if ((g + 1) % KS != 0) return;
         const int S = (g + 1) / KS;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (S + 1 < NS) issue_slot(S + 1);
+        if (S + 1 < ns) issue_slot(S + 1);
     };
     auto frag = [&](int g) { return wring + ((g / KS) % SLOTS) * SLOT_BYTES + (g % KS) * CH_STEP_BYTES + lane0 * 16; };
 
@@ -137,7 +142,9 @@ __global__ __launch_bounds__(512, 1) void resblock_chain_kernel(ChainParams p) {
         wb1 = (const unsigned char*)B.w1;
         wb2 = (const unsigned char*)B.w2;
         asm volatile("" : "+s"(wb1), "+s"(wb2));
-        const bool single = B.single != 0;
+        const int linkkind = B.single;
+        const bool single = linkkind != 0;
+        const int nchunk = linkkind == 2 ? B.nchunk : 1;
         if (single) { issue_slot(9); issue_slot(10); }      // (every wave is past the previous block's K loops: barrier A below)
         else { issue_slot(0); issue_slot(1); }
         C64Epi e1, e2;
@@ -147,9 +154,10 @@ __global__ __launch_bounds__(512, 1) void resblock_chain_kernel(ChainParams p) {
         e2 = e1;
         e2.scale = B.scale2; e2.shift = B.shift2; e2.alpha = B.alpha2;
         e2.act = B.act2; e2.act_param = B.act_param2; e2.alpha_pc = B.alpha_pc2;
+        if (linkkind == 2) { e2.mode = B.mode; e2.Cout = 64 * nchunk; e2.y = B.y; e2.out_cs = B.mode == C64_PLAIN ? 64 * nchunk : 64; }
         C64ParRegs pregs1, pregs2;
         c64_params_load(pregs1, e1, 1, tid);
-        c64_params_load(pregs2, e2, 1, tid);
+        c64_params_load(pregs2, e2, nchunk, tid);
         const bf16_t* src = kb == 0 ? p.x : (const bf16_t*)kp->blk[kb - 1].y;
         const bool halo_only = B.halo_only != 0;
         const __amdgpu_buffer_rsrc_t xres =
@@ -220,9 +228,105 @@ __global__ __launch_bounds__(512, 1) void resblock_chain_kernel(ChainParams p) {
                 if (((tid + i * NTH) >> 3) < NHP) *(u32x4*)(lds + lh[i]) = vh[i];
         }
         c64_params_store(par, pregs1, 1, tid);          // (the previous block's readers are past barrier A)
-        c64_params_store(par + 192, pregs2, 1, tid);
+        c64_params_store(par + 192, pregs2, nchunk, tid);
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // also retires weight slots 0, 1
         __builtin_amdgcn_s_barrier();                    // C: tile, parameters and the first two taps are in LDS
+
+        if (linkkind == 2) {
+            // ---- the LAST link: one conv 64 -> 64 * nchunk on the tile (the first Upsampler conv of Generator.forward, P/ops.py
+            // :74-78, with PixelShuffle as store addressing), conv_c64_kernel's chunk loop on the LDS-resident tile; plain stores:
+            // nobody reads them in this launch ----
+            if (B.xcopy) {
+                // NCHW f32 copy of the link's INPUT from the tile's centre (srmi_conv_args.x_copy; see conv_c64_kernel): a unit =
+                // (4 consecutive pixels of a tile row, 8 channels), four 16-byte LDS reads and eight 16-byte stores
+                constexpr int QPR = TW / 4;
+                constexpr int UNITS = 8 * TH * QPR;
+                const size_t plane = (size_t)p.H * p.W;
+                float* const dstn = B.xcopy + (size_t)n * 64 * plane;
+                for (int u = tid; u < UNITS; u += NTH) {
+                    const int oct = u & 7, t = u >> 3;
+                    const int r = t / QPR, qd = t - r * QPR;
+                    const int gy = y0 + r, gx = x0 + 4 * qd;
+                    if (gy < p.H && gx < p.W) {                    // W % 4 == 0 (checked on the host): whole quads
+                        u32x4 v[4];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const int P = (r + 2) * ROWP + 2 + 4 * qd + j;
+                            v[j] = *(const u32x4*)(lds + P * 128 + ((oct ^ c64_key(P)) << 4));
+                        }
+                        float* const d0 = dstn + (size_t)(8 * oct) * plane + (size_t)gy * p.W + gx;
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            f32x4 o;
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) {
+                                const unsigned w = v[j][c >> 1];
+                                o[j] = __builtin_bit_cast(float, (c & 1) ? (w & 0xffff0000u) : (w << 16));
+                            }
+                            *(f32x4*)(d0 + c * plane) = o;
+                        }
+                    }
+                }
+            }
+            auto wide = [&](auto P2, const int t2base) {
+                constexpr int PT2c = decltype(P2)::value;
+                int prow[PT2c], pcol[PT2c];
+                int boff2[PT2c][3];
+#pragma unroll
+                for (int k = 0; k < PT2c; ++k) {
+                    const int t = t2base + k;
+                    prow[k] = t / TWT;
+                    pcol[k] = (t - prow[k] * TWT) * 16;
+#pragma unroll
+                    for (int dx = 0; dx < 3; ++dx) {
+                        const int P = (prow[k] + 1) * ROWP + pcol[k] + pl + dx + 1;      // (x lies one pixel row and column inside the T window)
+                        boff2[k][dx] = P * 128 + ((q ^ c64_key(P)) << 4);
+                    }
+                }
+                bf16x8 afr[2][4], bfr2[2][PT2c];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) afr[0][t] = *(const bf16x8*)(frag(18) + t * 1024);
+#pragma unroll
+                for (int k = 0; k < PT2c; ++k) bfr2[0][k] = *(const bf16x8*)(lds + boff2[k][0]);
+#pragma unroll 1
+                for (int c = 0; c < nchunk; ++c) {
+                    f32x4 acc2[PT2c][4];
+#pragma unroll
+                    for (int k = 0; k < PT2c; ++k)
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) acc2[k][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    const int gb = 18 + 18 * c;
+                    const bool last = c + 1 == nchunk;
+#pragma unroll
+                    for (int j = 0; j < 18; ++j) {
+                        const int g = gb + j;
+                        if (j + 1 < 18 || !last) {      // (step 17 of a chunk prefetches step 0 of the next one: same pixels, tap 0)
+                            if ((j + 1) % KS == 0) handoff(g, 9 + 9 * nchunk);
+                            const unsigned char* wslot = frag(g + 1);
+#pragma unroll
+                            for (int t = 0; t < 4; ++t) afr[(j + 1) & 1][t] = *(const bf16x8*)(wslot + t * 1024);
+                            const int jn = (j + 1) % 18;
+                            const int tapn = jn >> 1, halfn = jn & 1;
+                            const int dyn = tapn / 3, dxn = tapn - 3 * dyn;
+#pragma unroll
+                            for (int k = 0; k < PT2c; ++k)
+                                bfr2[(j + 1) & 1][k] =
+                                    *(const bf16x8*)(lds + ((boff2[k][dxn] ^ (halfn << 6)) + dyn * (ROWP * 128)));
+                        }
+#pragma unroll
+                        for (int k = 0; k < PT2c; ++k)
+#pragma unroll
+                            for (int t = 0; t < 4; ++t)
+                                acc2[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[j & 1][t], bfr2[j & 1][k], acc2[k][t], 0, 0, 0);
+                        if (j + 1 < 18) sched_interleave<0, 4 + PT2c, 4 * PT2c>();
+                    }
+                    c64_epilogue<PT2c>(acc2, par + 192 * (1 + c), e2, c, n, y0, x0, prow, pcol, pl, q);
+                }
+            };
+            if (wave < NW / 2) wide(std::integral_constant<int, PT2>{}, wave * PT2);
+            else wide(std::integral_constant<int, PT2B>{}, (NW / 2) * PT2 + (wave - NW / 2) * PT2B);
+            break;          // (the last link: nothing to publish)
+        }
 
         auto body = [&](auto P1, auto P2, const int t1base, const int t2base) {
             constexpr int PT1c = decltype(P1)::value, PT2c = decltype(P2)::value;
@@ -258,7 +362,7 @@ __global__ __launch_bounds__(512, 1) void resblock_chain_kernel(ChainParams p) {
             for (int k = 0; k < PT1c; ++k) bfr[0][k] = *(const bf16x8*)(lds + boff1[k][0]);
 #pragma unroll
             for (int j = 0; j < 18; ++j) {
-                handoff(j);
+                handoff(j, NS);
                 {   // prefetch the fragments of global step j+1 (step 18 = first step of conv2: weights only)
                     const unsigned char* wslot = frag(j + 1);
 #pragma unroll
@@ -388,7 +492,7 @@ __global__ __launch_bounds__(512, 1) void resblock_chain_kernel(ChainParams p) {
             for (int j = 0; j < 18; ++j) {
                 const int g = 18 + j;
                 if (g + 1 < 36) {
-                    handoff(g);
+                    handoff(g, NS);
                     const unsigned char* wslot = frag(g + 1);
 #pragma unroll
                     for (int t = 0; t < 4; ++t) afr[(j + 1) & 1][t] = *(const bf16x8*)(wslot + t * 1024);
@@ -544,31 +648,54 @@ static bool chain_link_ok(const srmi_conv_args& a1, const srmi_conv_args& a2) {
     return true;
 }
 
-// a single conv right behind a chain that can run as its tail link: 3x3 64 -> 64 on the last block's output, plus a
-// dense bf16 residual that no block of the chain writes (conv02 + the long skip of Generator.forward, P/srgan_model.py:33-34)
-static bool chain_tail_ok(const srmi_conv_args* a, int L, const srmi_conv_args& t) {
+// a single conv right behind the chained pairs that can run as a tail link: 3x3 64 -> 64 on the previous link's output,
+// plus a dense bf16 residual that no block of the chain writes (conv02 + the long skip of Generator.forward,
+// P/srgan_model.py:33-34).  nprev = convs of the chain before it.
+static bool chain_tail_ok(const srmi_conv_args* a, int nprev, const srmi_conv_args& t) {
     const srmi_conv_desc& d = t.d;
     if (!(t.flags & SRMI_CONV_FUSE_CHAIN) || (t.flags & SRMI_CONV_FUSE_NEXT) || t.x_copy) return false;
     if (!c64_supported(d) || d.Cout != 64 || d.shuffle != 1) return false;
     if (d.N != a[0].d.N || d.H != a[0].d.H || d.W != a[0].d.W) return false;
     if ((d.in_cstride && d.in_cstride != 64) || (d.out_cstride && d.out_cstride != 64) || d.out_coffset) return false;
     if (d.res_cstride && d.res_cstride != 64) return false;
-    if (!t.x || t.x != a[2 * L - 1].y || !t.w || !t.y || !t.scale || !t.shift) return false;
+    if (!t.x || t.x != a[nprev - 1].y || !t.w || !t.y || !t.scale || !t.shift) return false;
     if (!t.residual || d.res_dtype != SRMI_BF16) return false;
     if (d.act == SRMI_ACT_PRELU && !t.alpha) return false;
     if (((uintptr_t)t.w | (uintptr_t)t.y | (uintptr_t)t.residual) & 15) return false;
     if (t.y == t.x || t.y == t.residual) return false;
-    for (int i = 0; i < L; ++i)
-        if (a[2 * i + 1].y == t.residual || a[2 * i + 1].y == t.y) return false;   // (the residual is read by plain loads; y must not be a live halo source)
+    for (int i = 1; i < nprev; i += 2)
+        if (a[i].y == t.residual || a[i].y == t.y) return false;   // (the residual is read by plain loads; y must not be a live halo source)
     return true;
 }
 
-// Convs of a[0 .. n) that can run as one chain starting at a[0]: L >= 2 ResBlock pairs (a[0], a[1]), (a[2], a[3]), ... and,
-// if one follows, a tail conv (*tail = true): 2 L (+ 1), or 0.  `fusable(a1, a2)` is api.hip's test for the fused ResBlock pair.
-int chain_run_length(const srmi_conv_args* a, int n, bool (*fusable)(const srmi_conv_args*, const srmi_conv_args*), bool* tail) {
-    if (tail) *tail = false;
+// the LAST link: a single conv 3x3 64 -> 64 * (1..4) on the previous link's output, any c64 store mode (PixelShuffle),
+// no residual, optionally with srmi_conv_args.x_copy (the first Upsampler conv of Generator.forward, P/ops.py:74-78)
+static bool chain_wide_ok(const srmi_conv_args* a, int nprev, const srmi_conv_args& t) {
+    const srmi_conv_desc& d = t.d;
+    if (!(t.flags & SRMI_CONV_FUSE_CHAIN) || (t.flags & SRMI_CONV_FUSE_NEXT)) return false;
+    if (!c64_supported(d) || d.Cout > 256) return false;
+    if (d.N != a[0].d.N || d.H != a[0].d.H || d.W != a[0].d.W) return false;
+    if (d.in_cstride && d.in_cstride != 64) return false;
+    const int Cf = d.Cout / (d.shuffle * d.shuffle);
+    if ((d.out_cstride && d.out_cstride != Cf) || d.out_coffset) return false;
+    if (!t.x || t.x != a[nprev - 1].y || !t.w || !t.y || !t.scale || !t.shift || t.residual) return false;
+    if (d.act == SRMI_ACT_PRELU && !t.alpha) return false;
+    if (((uintptr_t)t.w | (uintptr_t)t.y) & 15) return false;
+    if (t.x_copy && ((d.W & 3) || ((uintptr_t)t.x_copy & 15))) return false;
+    if (t.y == t.x) return false;
+    for (int i = 1; i < nprev; i += 2)
+        if (a[i].y == t.y) return false;
+    if (a[nprev - 1].y == t.y) return false;
+    return true;
+}
+
+// Convs of a[0 .. n) that can run as one chain starting at a[0]: L >= 2 ResBlock pairs (a[0], a[1]), (a[2], a[3]), ..., then
+// up to two single-conv tail links (*ntail: conv + residual, then the wide last link; either may be missing): 2 L + ntail,
+// or 0.  `fusable(a1, a2)` is api.hip's test for the fused ResBlock pair.
+int chain_run_length(const srmi_conv_args* a, int n, bool (*fusable)(const srmi_conv_args*, const srmi_conv_args*), int* npairs,
+                     int* kinds) {
     int L = 0;
-    while (L < CHAIN_MAX_BLOCKS - 1 && 2 * L + 1 < n) {
+    while (L < CHAIN_MAX_BLOCKS - 2 && 2 * L + 1 < n) {
         const srmi_conv_args& a1 = a[2 * L];
         const srmi_conv_args& a2 = a[2 * L + 1];
         if (!(a1.flags & SRMI_CONV_FUSE_NEXT) || !(a1.flags & SRMI_CONV_FUSE_CHAIN)) break;
@@ -589,15 +716,18 @@ int chain_run_length(const srmi_conv_args* a, int n, bool (*fusable)(const srmi_
         if (!cd) return 0;
         if (nb > cd->cus || nb * 4 > 4096) return 0;          // every workgroup must be resident at once (one per CU)
     }
-    const bool t = 2 * L < n && chain_tail_ok(a, L, a[2 * L]);
-    if (tail) *tail = t;
-    return 2 * L + (t ? 1 : 0);
+    int nc = 2 * L, nt = 0;
+    int k[2] = {0, 0};
+    if (nc < n && chain_tail_ok(a, nc, a[nc])) { k[nt++] = 1; ++nc; }
+    if (nc < n && chain_wide_ok(a, nc, a[nc])) { k[nt++] = 2; ++nc; }
+    if (npairs) *npairs = L;
+    if (kinds) { kinds[0] = k[0]; kinds[1] = k[1]; }
+    return nc;
 }
 
-// nconv = what chain_run_length returned for (a, .)
-int chain_launch(const srmi_conv_args* a, int nconv, hipStream_t s) {
-    const int L = nconv / 2;
-    const bool tail = (nconv & 1) != 0;
+int chain_launch(const srmi_conv_args* a, int npairs, const int* kinds, hipStream_t s) {
+    const int L = npairs;
+    const int ntail = (kinds[0] ? 1 : 0) + (kinds[1] ? 1 : 0);
     const srmi_conv_desc& d = a[0].d;
     if (d.N == 0 || d.H == 0 || d.W == 0) return SRMI_OK;
     std::lock_guard<std::mutex> lk(g_chain_mu);
@@ -614,7 +744,7 @@ int chain_launch(const srmi_conv_args* a, int nconv, hipStream_t s) {
     p.flags = cd->flags; p.status = cd->status_dev;
     p.N = d.N; p.H = d.H; p.W = d.W;
     p.tiles_x = (d.W + 47) / 48; p.tiles_y = (d.H + 11) / 12;
-    p.nblk = L + (tail ? 1 : 0);
+    p.nblk = L + ntail;
     for (int i = 0; i < L; ++i) {
         const srmi_conv_args& a1 = a[2 * i];
         const srmi_conv_args& a2 = a[2 * i + 1];
@@ -625,19 +755,26 @@ int chain_launch(const srmi_conv_args* a, int nconv, hipStream_t s) {
         B.y = (bf16_t*)a2.y;
         B.act1 = a1.d.act; B.act_param1 = a1.d.act_param; B.alpha_pc1 = a1.d.alpha_per_channel;
         B.act2 = a2.d.act; B.act_param2 = a2.d.act_param; B.alpha_pc2 = a2.d.alpha_per_channel;
-        B.halo_only = (i + 1 < L + (tail ? 1 : 0)) && (a1.flags & SRMI_CONV_Y_TRANSIENT) ? 1 : 0;
+        B.halo_only = (i + 1 < L + ntail) && (a1.flags & SRMI_CONV_Y_TRANSIENT) ? 1 : 0;
     }
-    if (tail) {
-        const srmi_conv_args& t = a[2 * L];
-        ChainBlk& B = p.blk[L];
-        B.single = 1;
+    for (int j = 0; j < ntail; ++j) {
+        const srmi_conv_args& t = a[2 * L + j];
+        ChainBlk& B = p.blk[L + j];
+        B.single = kinds[j];
         B.w2 = (const bf16_t*)t.w;
         B.scale2 = t.scale; B.shift2 = t.shift; B.alpha2 = t.alpha;
         B.y = (bf16_t*)t.y;
-        B.res = (const bf16_t*)t.residual;
         B.act2 = t.d.act; B.act_param2 = t.d.act_param; B.alpha_pc2 = t.d.alpha_per_channel;
         // (conv "1"'s parameters are loaded but never used: point them at valid memory)
         B.scale1 = t.scale; B.shift1 = t.shift; B.alpha1 = t.alpha; B.act1 = SRMI_ACT_NONE;
+        if (kinds[j] == 1) {
+            B.res = (const bf16_t*)t.residual;
+            B.halo_only = (j + 1 < ntail) && (t.flags & SRMI_CONV_Y_TRANSIENT) ? 1 : 0;
+        } else {
+            B.nchunk = t.d.Cout / 64;
+            B.mode = t.d.shuffle == 1 ? C64_PLAIN : (t.d.shuffle_order == SRMI_SHUFFLE_DCR ? C64_DCR : C64_CRD);
+            B.xcopy = t.x_copy;
+        }
     }
     const unsigned nb = (unsigned)(p.N * p.tiles_x * p.tiles_y);
     // two persistent grids at once would each hold half the CUs and wait for the other half: a chain launch on another

@@ -120,7 +120,7 @@ class _Seq:
         self.keep += [wp, scale, shift]
         self.layers.append((desc, x, wp, scale, shift, alpha, residual, y,
                             (L.CONV_FUSE_NEXT if fuse_next else 0) | (L.CONV_FUSE_CHAIN if chain and _FUSE_CHAIN else 0)
-                            | (L.CONV_Y_TRANSIENT if fuse_next and chain and y_transient and _FUSE_CHAIN else 0)))
+                            | (L.CONV_Y_TRANSIENT if chain and y_transient and _FUSE_CHAIN else 0)))
         self.kernels.append(L.kernel_name(desc))
         return y
 
@@ -210,15 +210,23 @@ class GeneratorPlan:
             s.add(blk.body[1], tmp, out, N, H, W, residual=cur)
             cur = out
         feat = s.buf(N, H, W, nf)
-        s.add(gen.conv02, cur, feat, N, H, W, residual=skip, chain=True)      # P/srgan_model.py:33-34 (the chain's tail link)
+        # `feat` leaves as NCHW f32 (P/srgan_model.py:39).  The first Upsampler conv holds it in LDS anyway: when that conv
+        # is a plain c64_bf16 launch, or the last link of the chained trunk, it writes the caller's copy on the side
+        # (srmi_conv_args.x_copy) and the separate re-layout pass disappears - inside the chain the NHWC bf16 `feat` is then
+        # read by the next link only (y_transient).  Otherwise (f32 compute, a single Upsampler fused into the tail, odd
+        # widths) the stand-alone srmi_layout_convert runs.
+        want_xcopy = compute == L.COMPUTE_BF16 and W % 4 == 0 and nf == 64 and _X_COPY
+        s.add(gen.conv02, cur, feat, N, H, W, residual=skip, chain=True, y_transient=want_xcopy)   # P/srgan_model.py:33-34 (a tail link of the chain)
         x, h, w = feat, H, W
         for j, up in enumerate(gen.tail):          # Upsampler, P/ops.py:74-78
             r = up.body[1].upscale_factor
             c2d = up.body[0].body[0]
             act = up.body[2] if len(up.body) > 2 else None
             y = s.buf(N, h * r, w * r, c2d.out_channels // (r * r))
-            # the last Upsampler and last_conv may run as ONE launch (its 4x-resolution output never reaches HBM)
-            s.add((c2d, None, act), x, y, N, h, w, shuffle=r, fuse_next=(j == len(gen.tail) - 1))
+            # the last Upsampler and last_conv may run as ONE launch (its 4x-resolution output never reaches HBM); the first
+            # one of two may be the chain's last link
+            last = j == len(gen.tail) - 1
+            s.add((c2d, None, act), x, y, N, h, w, shuffle=r, fuse_next=last, chain=(j == 0 and not last))
             x, h, w = y, h * r, w * r
         self.sr_shape = (N, img, h, w)
         sr0 = torch.empty(self.sr_shape, dtype=torch.float32, device=dev)   # placeholder; run() allocates fresh outputs
@@ -231,15 +239,15 @@ class GeneratorPlan:
         self._seq = s
         self.args[0].x = skip.data_ptr()          # placeholder so fusability can be queried before run()
         self.launches = _Seq.launches(self.args, self.n, self.kernels)
-        # `feat` leaves as NCHW f32 (P/srgan_model.py:39).  The first Upsampler conv stages it in LDS anyway: when that
-        # launch is a plain c64_bf16 one it writes the caller's copy on the side (srmi_conv_args.x_copy) and the separate
-        # re-layout pass disappears; otherwise (f32 compute, a single Upsampler fused into the tail, odd widths) the
-        # stand-alone srmi_layout_convert runs.
         self.feat_idx = None
-        if compute == L.COMPUTE_BF16 and W % 4 == 0 and nf == 64 and _X_COPY:
+        if want_xcopy:
             idx = self.n - 1 - len(gen.tail)                     # the conv that reads feat: first conv of the tail
-            if any(lbl == "c64_bf16" and i0 == idx and cnt == 1 for (lbl, i0, cnt) in self.launches):
-                self.feat_idx = idx
+            for (lbl, i0, cnt) in self.launches:
+                if (lbl == "c64_bf16" and i0 == idx and cnt == 1) or (lbl == "resblock_chain_bf16" and i0 + cnt - 1 == idx):
+                    self.feat_idx = idx
+            if self.feat_idx is None:
+                # nobody writes the NCHW copy: the NHWC tensor must be whole for srmi_layout_convert
+                self.args[idx - 1].flags &= ~L.CONV_Y_TRANSIENT
 
     def run(self, x):
         x = x.contiguous()

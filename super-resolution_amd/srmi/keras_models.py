@@ -187,11 +187,12 @@ class KerasSRGANPlan(_Plan):
         cur, tmp, ping = first, s.buf(N, H, W, nf), [s.buf(N, H, W, nf), s.buf(N, H, W, nf)]
         for i, blk in enumerate(m.blocks):
             out = ping[i & 1]
-            s.add((blk.conv1, blk.bn1, blk.act), cur, tmp, N, H, W, fuse_next=True)     # one fused launch per block
+            # one fused launch per block, or - where the whole grid fits the GPU - all blocks and `post` as one chained launch
+            s.add((blk.conv1, blk.bn1, blk.act), cur, tmp, N, H, W, fuse_next=True, chain=True, y_transient=True)
             s.add((blk.conv2, blk.bn2, None), tmp, out, N, H, W, residual=cur)
             cur = out
         t = s.buf(N, H, W, nf)
-        s.add((m.post, m.post_bn, None), cur, t, N, H, W, residual=first)
+        s.add((m.post, m.post_bn, None), cur, t, N, H, W, residual=first, chain=True)
         x, h, w = t, H, W
         for j in range(2):
             y = s.buf(N, 2 * h, 2 * w, nf)

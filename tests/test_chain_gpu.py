@@ -54,7 +54,7 @@ def _run(arr, n, flags):
     dict(N=3, H=12, W=65, nblk=2),                    # one tile row, second tile column one pixel wide + its halo
     dict(N=1, H=13, W=100, nblk=5, alphas=[0.25, -0.3, 1.0, 0.0]),   # one-pixel second tile row; compare + select slopes
     dict(N=4, H=60, W=144, nblk=6, act2=L.ACT_LRELU),                # 60 workgroups; an activation on the second conv
-    dict(N=1, H=180, W=192, nblk=23),                 # 60 workgroups, the longest chain of one launch
+    dict(N=1, H=180, W=192, nblk=22),                 # 60 workgroups, the longest run of pairs in one launch
 ])
 def test_chain_equals_launch_per_block(case):
     lib = L.load()
@@ -141,6 +141,85 @@ def test_chain_with_tail_conv(case):
     assert lib.srmi_conv2d_chain_length(arr, n) == n - 1
 
 
+@pytest.mark.parametrize("case", [
+    dict(N=16, H=96, W=96, nblk=16, cout=256, r=2, xcopy=True, tail1=True),      # cfg1: trunk + conv02 + first Upsampler conv
+    dict(N=2, H=50, W=72, nblk=2, cout=256, r=2, dcr=True, alpha_pc=True, xcopy=True, tail1=True),
+    dict(N=1, H=25, W=130, nblk=3, cout=128, r=1, tail1=False),                  # wide link right behind the pairs, plain store
+    dict(N=3, H=12, W=65, nblk=2, cout=64, r=1, tail1=True),
+    dict(N=1, H=40, W=100, nblk=2, cout=192, r=1, xcopy=True, tail1=True),
+])
+def test_chain_with_wide_last_link(case):
+    """... + a conv to 64..256 channels (PixelShuffle in the store addressing, optional NCHW f32 copy of its input) as the
+    chain's last link, against the same sequence one launch per conv: every written tensor bit-identical."""
+    lib = L.load()
+    N, H, W, nblk = case["N"], case["H"], case["W"], case["nblk"]
+    arr0, bufs, tmp, keep = _build(N, H, W, nblk, seed=31)
+    ntail = 2 if case["tail1"] else 1
+    n = 2 * nblk + ntail
+    arr = (L.ConvArgs * n)()
+    for i in range(2 * nblk):
+        C.memmove(C.byref(arr[i]), C.byref(arr0[i]), C.sizeof(L.ConvArgs))
+    g = np.random.default_rng(8)
+    cur = bufs[-1]
+    feat = None
+    if case["tail1"]:
+        d = Fn.make_desc(N, H, W, 64, 64, 3, in_dtype=L.BF16, out_dtype=L.BF16, res_dtype=L.BF16, compute=L.COMPUTE_BF16, act=L.ACT_NONE)
+        w = torch.from_numpy((g.standard_normal((64, 64, 3, 3)) / 30.0).astype(np.float32)).to(DEV)
+        wp = Fn.pack_weights(d, w)
+        sc = torch.from_numpy(g.uniform(0.5, 1.2, 64).astype(np.float32)).to(DEV)
+        sh = torch.from_numpy(g.uniform(-0.2, 0.2, 64).astype(np.float32)).to(DEV)
+        feat = torch.full((N, H, W, 64), 7.0, dtype=torch.bfloat16, device=DEV)
+        Fn.fill_args(arr[2 * nblk], d, cur, wp, sc, sh, None, keep[0], feat)
+        keep += [wp, sc, sh]
+        cur = feat
+    cout, r = case["cout"], case["r"]
+    apc = 1 if case.get("alpha_pc") else 0
+    du = Fn.make_desc(N, H, W, 64, cout, 3, in_dtype=L.BF16, out_dtype=L.BF16, res_dtype=L.BF16, compute=L.COMPUTE_BF16,
+                      act=L.ACT_PRELU, alpha_per_channel=apc, shuffle=r,
+                      shuffle_order=L.SHUFFLE_DCR if case.get("dcr") else L.SHUFFLE_CRD)
+    wu = torch.from_numpy((g.standard_normal((cout, 64, 3, 3)) / 30.0).astype(np.float32)).to(DEV)
+    wpu = Fn.pack_weights(du, wu)
+    scu = torch.from_numpy(g.uniform(0.5, 1.2, cout).astype(np.float32)).to(DEV)
+    shu = torch.from_numpy(g.uniform(-0.2, 0.2, cout).astype(np.float32)).to(DEV)
+    alu = torch.from_numpy(g.uniform(-0.2, 0.6, cout if apc else 1).astype(np.float32)).to(DEV)
+    up = torch.full((N, H * r, W * r, cout // (r * r)), 5.0, dtype=torch.bfloat16, device=DEV)
+    Fn.fill_args(arr[n - 1], du, cur, wpu, scu, shu, alu, None, up)
+    xc = torch.full((N, 64, H, W), -3.0, dtype=torch.float32, device=DEV) if case.get("xcopy") else None
+    if xc is not None:
+        arr[n - 1].x_copy = xc.data_ptr()
+
+    def run(chain):
+        for i in range(0, 2 * nblk, 2):
+            arr[i].flags = L.CONV_FUSE_NEXT | ((L.CONV_FUSE_CHAIN | L.CONV_Y_TRANSIENT) if chain else 0)
+        for i in range(2 * nblk, n):
+            arr[i].flags = (L.CONV_FUSE_CHAIN | L.CONV_Y_TRANSIENT) if chain else 0
+        L.check(lib.srmi_conv2d_fwd_seq(arr, n, Fn.stream_ptr()))
+        torch.cuda.synchronize()
+
+    run(False)
+    ref_up = up.clone()
+    ref_xc = xc.clone() if xc is not None else None
+    up.fill_(-2.0)
+    if xc is not None:
+        xc.fill_(9.0)
+    if feat is not None:
+        feat.fill_(4.0)
+    for i in range(n):
+        arr[i].flags = L.CONV_FUSE_CHAIN | (L.CONV_FUSE_NEXT if i < 2 * nblk and i % 2 == 0 else 0)
+    assert lib.srmi_conv2d_chain_length(arr, n) == n
+    run(True)
+    assert lib.srmi_chain_status() == 0
+    assert torch.equal(ref_up, up), int((ref_up != up).sum())
+    if xc is not None:
+        assert torch.equal(ref_xc, xc)
+    if feat is not None:
+        # conv02's output was transient: only the tile borders reached memory
+        yy = torch.arange(H, device=DEV) % 12
+        xx = torch.arange(W, device=DEV) % 48
+        border = ((yy < 2) | (yy >= 10))[:, None] | ((xx < 2) | (xx >= 46))[None, :]
+        assert torch.all(feat[:, ~border] == 4.0)
+
+
 def test_chain_refused_shapes_fall_back():
     """More workgroups than CUs, narrow images, a foreign residual: no chain, same results through single launches."""
     lib = L.load()
@@ -156,11 +235,12 @@ def test_chain_refused_shapes_fall_back():
     got = bufs[-1].clone()
     _run(arr, 6, L.CONV_FUSE_NEXT)
     assert torch.equal(got, bufs[-1])
-    # 24 blocks: 23 go out as one chain, the last one as a fused pair of its own
+    # 24 blocks: 22 go out as one chain, the last two as a second one
     arr, bufs, tmp, keep = _build(1, 24, 96, 24, seed=12)
     for i in range(0, 48, 2):
         arr[i].flags = L.CONV_FUSE_NEXT | L.CONV_FUSE_CHAIN
-    assert lib.srmi_conv2d_chain_length(arr, 48) == 46
+    assert lib.srmi_conv2d_chain_length(arr, 48) == 44
+    assert lib.srmi_conv2d_chain_length(C.byref(arr[44]), 4) == 4
     _run(arr, 48, L.CONV_FUSE_NEXT | L.CONV_FUSE_CHAIN | L.CONV_Y_TRANSIENT)
     got = bufs[-1].clone()
     _run(arr, 48, L.CONV_FUSE_NEXT)
@@ -191,7 +271,7 @@ def test_generator_chain_switch():
     with torch.no_grad():
         sr1, f1 = gen(x)
         plan = gen._plans.get(gen, 2, 48, 96, 1)
-        assert any(lbl == "resblock_chain_bf16" and cnt == 11 for (lbl, i0, cnt) in plan.launches), plan.launches
+        assert any(lbl == "resblock_chain_bf16" and cnt == 12 for (lbl, i0, cnt) in plan.launches), plan.launches
         engine.set_fuse_chain(False)
         try:
             engine.invalidate(gen)
