@@ -420,7 +420,7 @@ def main():
             e[0] += 1; e[1] += kms[u]; e[2] += fl
             if label == dom:
                 flops += fl; t_dom += kms[u] * 1e-3; n_dom += 1
-                n_blocks += fl / (2 * conv_flops(plan.args[i].d))     # (a chain's tail convs count by their FLOPs: 0.5 and 2 blocks)
+                n_blocks += fl / (2 * conv_flops(plan.args[i + 1].d))     # (a chain's head and tail convs count by their FLOPs)
             if label in fam:
                 f_fam += fl; t_fam += kms[u] * 1e-3
         achieved = flops / t_dom / 1e12

@@ -147,7 +147,12 @@ typedef struct srmi_conv_args {
                                  (conv02 + the long skip add of Generator.forward, P/srgan_model.py:33-34; it honours
                                  SRMI_CONV_Y_TRANSIENT when the next link follows), then - always last - a 3x3 conv
                                  64 -> 64..256 on the previous link's y, any shuffle / store mode of "c64_bf16", no
-                                 residual, x_copy allowed (the first Upsampler conv, P/ops.py:74-78).  Either may be absent. */
+                                 residual, x_copy allowed (the first Upsampler conv, P/ops.py:74-78).  Either may be absent.
+                                 HEAD LINK: the flag (without SRMI_CONV_FUSE_NEXT) on the conv right in front of the first
+                                 chained pair lets it run as the chain's first link when it is a "k9c3_bf16" conv (9x9,
+                                 <= 3 input channels in any layout that kernel reads, 64 dense bf16 output channels = the
+                                 first pair's x, no residual): conv01 of Generator.forward, P/srgan_model.py:29.  Its y is
+                                 written in full. */
 #define SRMI_CONV_Y_TRANSIENT 4 /* with SRMI_CONV_FUSE_CHAIN on the first conv of a pair: the pair's output y (conv2->y) is read
                                  ONLY by the next pair of the sequence, so when both run inside one chained launch y need
                                  not be written in full: the launch stores just the two outermost pixel rows and columns of
@@ -227,7 +232,7 @@ int srmi_resblock_fwd(const srmi_conv_args* conv1, const srmi_conv_args* conv2, 
  * loop over modules). */
 int srmi_chain_status(void);
 
-/* Number of convs (2 x blocks [+ up to 2 tail convs], >= 4) that srmi_conv2d_fwd_seq(a, n, .) would run as ONE
+/* Number of convs ([head conv +] 2 x blocks [+ up to 2 tail convs], >= 4) that srmi_conv2d_fwd_seq(a, n, .) would run as ONE
  * SRMI_CONV_FUSE_CHAIN launch starting at a[0]; 0 if a[0] starts no chain (then it goes out as a fused pair or a single
  * conv). */
 int srmi_conv2d_chain_length(const srmi_conv_args* a, int32_t n);

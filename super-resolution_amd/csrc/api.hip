@@ -340,18 +340,18 @@ int srmi_chain_status(void) { return chain_status(); }
 
 int srmi_conv2d_chain_length(const srmi_conv_args* a, int32_t n) {
     if (!a || n < 4) return 0;
-    if (!(a[0].flags & SRMI_CONV_FUSE_NEXT) || !(a[0].flags & SRMI_CONV_FUSE_CHAIN)) return 0;
+    if (!(a[0].flags & SRMI_CONV_FUSE_CHAIN)) return 0;
     return chain_run_length(a, n, can_fuse_pair);
 }
 
 int srmi_conv2d_fwd_seq(const srmi_conv_args* a, int32_t n, void* stream) {
     if (n < 0 || (n > 0 && !a)) { set_error("fwd_seq: bad arguments"); return SRMI_EINVAL; }
     for (int32_t i = 0; i < n; ++i) {
-        if ((a[i].flags & SRMI_CONV_FUSE_NEXT) && (a[i].flags & SRMI_CONV_FUSE_CHAIN)) {
-            int npairs = 0, kinds[2] = {0, 0};
-            const int nc = chain_run_length(a + i, n - i, can_fuse_pair, &npairs, kinds);
+        if (a[i].flags & SRMI_CONV_FUSE_CHAIN) {         // the first pair of a chain, or the head link in front of one
+            int npairs = 0, kinds[2] = {0, 0}, head = 0;
+            const int nc = chain_run_length(a + i, n - i, can_fuse_pair, &npairs, kinds, &head);
             if (nc >= 4) {
-                int rc = chain_launch(a + i, npairs, kinds, (hipStream_t)stream);
+                int rc = chain_launch(a + i, head, npairs, kinds, (hipStream_t)stream);
                 if (rc) return rc;
                 i += nc - 1;
                 continue;

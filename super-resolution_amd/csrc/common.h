@@ -141,8 +141,8 @@ bool resblock_supported(const srmi_conv_desc& d1, const srmi_conv_desc& d2);
 int resblock_launch(const srmi_conv_args& a1, const srmi_conv_args& a2, hipStream_t s);
 // chain of fused ResBlocks in one persistent launch (conv_chain_bf16.hip)
 int chain_run_length(const srmi_conv_args* a, int n, bool (*fusable)(const srmi_conv_args*, const srmi_conv_args*),
-                     int* npairs = nullptr, int* kinds = nullptr);
-int chain_launch(const srmi_conv_args* a, int npairs, const int* kinds, hipStream_t s);
+                     int* npairs = nullptr, int* kinds = nullptr, int* head = nullptr);
+int chain_launch(const srmi_conv_args* a, int head, int npairs, const int* kinds, hipStream_t s);
 int chain_status();
 // fused generator tail: up conv 64->256 + PixelShuffle(2) + PReLU + last conv 64->3 + tanh (conv_upfuse_bf16.hip)
 bool upfuse_supported(const srmi_conv_desc& d1, const srmi_conv_desc& d2);

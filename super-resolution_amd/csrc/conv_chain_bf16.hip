@@ -40,8 +40,17 @@ struct ChainBlk {      // what changes from block to block
     float* xcopy;       // single == 2: NULL, or the link's input as [N, 64, H, W] f32 (srmi_conv_args.x_copy)
 };
 
+struct ChainHead {     // optional first link: the 9x9 conv from <= 3 image channels (conv01 of Generator.forward, P/srgan_model.py:29)
+    const void* x; const bf16_t* w;        // the caller's image tensor; weights as k9c3_pack lays them out (72 KiB)
+    const float* scale; const float* shift; const float* alpha;
+    bf16_t* y;                             // its output (block 0's input), written in full
+    int on, Cin, in_cs, in_nchw, in_bf16;
+    int act; float act_param; int alpha_pc;
+};
+
 struct ChainParams {
-    const bf16_t* x;       // input of block 0
+    ChainHead head;
+    const bf16_t* x;       // input of block 0 (no head link)
     unsigned* flags;       // [tiles] blocks published by each tile; zeroed on the stream before the launch
     unsigned* status;      // sticky give-up word (host-mapped)
     int N, H, W, tiles_x, tiles_y, nblk;
@@ -127,6 +136,185 @@ __global__ __launch_bounds__(512, 1) void resblock_chain_kernel(ChainParams p) {
     };
     auto frag = [&](int g) { return wring + ((g / KS) % SLOTS) * SLOT_BYTES + (g % KS) * CH_STEP_BYTES + lane0 * 16; };
 
+    const int fbase = p.head.on ? 1 : 0;     // flag value = links published: the head link counts as one
+    if (p.head.on) {
+        // ================= head link: conv 9x9 from <= 3 channels on this workgroup's 12 x 48 pixels (conv_k9c3_kernel's
+        // arithmetic: K = 9 tap rows x 16 tap columns x 4 channels, zero-weight padding), its halo comes from the
+        // neighbours like every later block's.  LDS during this phase: [72 KiB weights | 20 x 64 x 4 bf16 input tile],
+        // all inside the (still empty) x tile region ==========================================================
+        const ChainHead& Hd = p.head;
+        int tid;
+        asm volatile("v_mov_b32 %0, %1" : "=v"(tid) : "v"(tid0));
+        const int lane = tid & 63;
+        const int pl = lane & 15, q = lane >> 4;
+        constexpr int K9W = 72 * 1024, ROWP9 = TW + 16, ROWS9 = TH + 8;
+        static_assert(K9W + ROWS9 * ROWP9 * 8 <= IN_BYTES, "head link's weights and input tile fit the x tile region");
+        unsigned char* const wl = lds;
+        unsigned char* const tile = lds + K9W;
+        {
+            const unsigned char* wsrc = (const unsigned char*)Hd.w + wave * 9 * 1024 + lane * 16;
+            const unsigned dst0 = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)(lptr_t)wl + (unsigned)(wave * 9 * 1024));
+#pragma unroll
+            for (int i = 0; i < 9; ++i) {
+                unsigned keep;
+                asm volatile(
+                    "s_mov_b32 %0, m0\n\t"
+                    "s_mov_b32 m0, %2\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %1, off\n\t"
+                    "s_mov_b32 m0, %0"
+                    : "=&s"(keep)
+                    : "v"(wsrc + i * 1024), "s"(dst0 + (unsigned)(i * 1024))
+                    : "memory");
+            }
+        }
+        C64Epi eh;
+        eh.scale = Hd.scale; eh.shift = Hd.shift; eh.alpha = Hd.alpha; eh.res = nullptr; eh.y = nullptr;
+        eh.H = p.H; eh.W = p.W; eh.Cout = 64; eh.out_cs = 64; eh.out_co = 0; eh.mode = C64_PLAIN;
+        eh.act = Hd.act; eh.act_param = Hd.act_param; eh.alpha_pc = Hd.alpha_pc;
+        C64ParRegs pregs;
+        c64_params_load(pregs, eh, 1, tid);
+        {
+            constexpr int NPIX = ROWS9 * ROWP9;
+            constexpr int NIT = (NPIX + NTH - 1) / NTH;
+            float v[NIT][3];
+            const size_t HW = (size_t)p.H * p.W;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = min(tid + it * NTH, NPIX - 1);
+                const int row = idx / ROWP9, col = idx - row * ROWP9;
+                const int gy = min(max(y0 - 4 + row, 0), p.H - 1), gx = min(max(x0 - 4 + col, 0), p.W - 1);
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int cc = c < Hd.Cin ? c : 0;
+                    const size_t gi = Hd.in_nchw ? ((size_t)n * Hd.Cin + cc) * HW + (size_t)gy * p.W + gx
+                                                 : (((size_t)n * p.H + gy) * p.W + gx) * Hd.in_cs + cc;
+                    v[it][c] = Hd.in_bf16 ? bf2f(((const bf16_t*)Hd.x)[gi]) : ((const float*)Hd.x)[gi];
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int idx = tid + it * NTH;
+                const int row = idx / ROWP9, col = idx - row * ROWP9;
+                const int gy = y0 - 4 + row, gx = x0 - 4 + col;
+                const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                u32x2 o;
+                o[0] = ok ? pack_bf2(v[it][0], Hd.Cin > 1 ? v[it][1] : 0.f) : 0u;
+                o[1] = ok ? pack_bf2(Hd.Cin > 2 ? v[it][2] : 0.f, 0.f) : 0u;
+                if (idx < NPIX) *(u32x2*)(tile + idx * 8) = o;
+            }
+        }
+        c64_params_store(par, pregs, 1, tid);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const __amdgpu_buffer_rsrc_t yres =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(Hd.y + (size_t)n * p.H * p.W * 64), 0, img_bytes, 0x00020000);
+        auto head = [&](auto P2, const int t2base) {
+            constexpr int PTc = decltype(P2)::value;
+            int prow[PTc], pcol[PTc], boff[PTc];
+#pragma unroll
+            for (int k = 0; k < PTc; ++k) {
+                const int t = t2base + k;
+                prow[k] = t / TWT;
+                pcol[k] = (t - prow[k] * TWT) * 16;
+                boff[k] = (prow[k] * ROWP9 + pcol[k] + pl + 2 * q) * 8;
+            }
+            f32x4 acc[PTc][4];
+#pragma unroll
+            for (int k = 0; k < PTc; ++k)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) acc[k][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            typedef union { u32x2 h[2]; bf16x8 v; } frag_t;
+            bf16x8 afr[2][4];
+            frag_t bfr[2][PTc];
+            const unsigned char* wlane = wl + lane * 16;
+#pragma unroll
+            for (int t = 0; t < 4; ++t) afr[0][t] = *(const bf16x8*)(wlane + t * 1024);
+#pragma unroll
+            for (int k = 0; k < PTc; ++k) {
+                bfr[0][k].h[0] = *(const u32x2*)(tile + boff[k]);
+                bfr[0][k].h[1] = *(const u32x2*)(tile + boff[k] + 8);
+            }
+#pragma unroll
+            for (int j = 0; j < 18; ++j) {     // K step j = (tap row ky = j >> 1, tap-column half h = j & 1)
+                if (j + 1 < 18) {
+                    const int kyn = (j + 1) >> 1, hn = (j + 1) & 1;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) afr[(j + 1) & 1][t] = *(const bf16x8*)(wlane + ((j + 1) * 4 + t) * 1024);
+#pragma unroll
+                    for (int k = 0; k < PTc; ++k) {
+                        const unsigned char* a = tile + boff[k] + (kyn * ROWP9 + 8 * hn) * 8;
+                        bfr[(j + 1) & 1][k].h[0] = *(const u32x2*)a;
+                        bfr[(j + 1) & 1][k].h[1] = *(const u32x2*)(a + 8);
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < PTc; ++k)
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[j & 1][t], bfr[j & 1][k].v, acc[k][t], 0, 0, 0);
+                if (j + 1 < 18) sched_interleave<0, 4 + 2 * PTc, 4 * PTc>();
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();           // every wave has finished reading the weights and the image tile
+            f32x2 sc[8], sh[8], sl[8];
+#pragma unroll
+            for (int hi = 0; hi < 2; ++hi)
+#pragma unroll
+                for (int v4 = 0; v4 < 2; ++v4) {
+                    const int c = 32 * hi + 8 * q + 4 * v4;
+                    const f32x4 a = *(const f32x4*)(par + c);
+                    const f32x4 bsh = *(const f32x4*)(par + 64 + c);
+                    const f32x4 csl = *(const f32x4*)(par + 128 + c);
+#pragma unroll
+                    for (int e = 0; e < 2; ++e) {
+                        sc[4 * hi + 2 * v4 + e] = (f32x2){a[2 * e], a[2 * e + 1]};
+                        sh[4 * hi + 2 * v4 + e] = (f32x2){bsh[2 * e], bsh[2 * e + 1]};
+                        sl[4 * hi + 2 * v4 + e] = (f32x2){csl[2 * e], csl[2 * e + 1]};
+                    }
+                }
+            auto epi = [&](auto KIND) {
+#pragma unroll
+                for (int k = 0; k < PTc; ++k) {
+                    u32x4 o0, o1;
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int j = 2 * t + e;
+                            const f32x2 a = {acc[k][t][2 * e], acc[k][t][2 * e + 1]};
+                            f32x2 v;
+                            if constexpr (decltype(KIND)::value == 2) v = slope_act2(a, sc[j], sh[j], sl[j]);
+                            else if constexpr (decltype(KIND)::value == 1) v = slope_act2_max(a, sc[j], sh[j], sl[j]);
+                            else v = __builtin_elementwise_fma(a, sc[j], sh[j]);
+                            const unsigned o = pack_bf2(v[0], v[1]);
+                            if (t < 2) o0[j & 3] = o; else o1[j & 3] = o;
+                        }
+                    const int oy = y0 + prow[k], ox = x0 + pcol[k] + pl;
+                    const bool ok = oy < p.H && ox < p.W;
+                    if (!ok) { o0 = (u32x4){0u, 0u, 0u, 0u}; o1 = o0; }
+                    const int P = (prow[k] + 2) * ROWP + pcol[k] + pl + 2;
+                    const int ra = P * 128 + ((q ^ c64_key(P)) << 4);
+                    *(u32x4*)(lds + ra) = o0;
+                    *(u32x4*)(lds + (ra ^ 64)) = o1;
+                    const unsigned off = ok ? (unsigned)oy * row_bytes + (unsigned)ox * 128u + 16u * q : OOB;
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_t, o0), yres, off, 0, SC1);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u_t, o1), yres, off + 64, 0, SC1);
+                }
+            };
+            const int kind = c64_slope_kind(eh);
+            if (kind == 0) epi(std::integral_constant<int, 0>{});
+            else if (kind == 1) epi(std::integral_constant<int, 1>{});
+            else epi(std::integral_constant<int, 2>{});
+        };
+        if (wave < NW / 2) head(std::integral_constant<int, PT2>{}, wave * PT2);
+        else head(std::integral_constant<int, PT2B>{}, (NW / 2) * PT2 + (wave - NW / 2) * PT2B);
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (tid0 == 0) __hip_atomic_store(p.flags + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+
     // the per-block table is read from the kernel-argument segment by scalar loads (indexing the by-value struct with the
     // loop counter would make hipcc copy it to scratch)
     typedef __attribute__((address_space(4))) const ChainParams* kparams_t;
@@ -158,13 +346,13 @@ __global__ __launch_bounds__(512, 1) void resblock_chain_kernel(ChainParams p) {
         C64ParRegs pregs1, pregs2;
         c64_params_load(pregs1, e1, 1, tid);
         c64_params_load(pregs2, e2, nchunk, tid);
-        const bf16_t* src = kb == 0 ? p.x : (const bf16_t*)kp->blk[kb - 1].y;
+        const bf16_t* src = kb == 0 ? (fbase ? (const bf16_t*)p.head.y : p.x) : (const bf16_t*)kp->blk[kb - 1].y;
         const bool halo_only = B.halo_only != 0;
         const __amdgpu_buffer_rsrc_t xres =
             __builtin_amdgcn_make_buffer_rsrc((void*)(src + (size_t)n * p.H * p.W * 64), 0, img_bytes, 0x00020000);
         const __amdgpu_buffer_rsrc_t yres =
             __builtin_amdgcn_make_buffer_rsrc((void*)(B.y + (size_t)n * p.H * p.W * 64), 0, img_bytes, 0x00020000);
-        if (kb == 0) {
+        if (kb + fbase == 0) {
             // ---- block 0: stage the whole x halo tile; pixels outside the image read as zeros through the descriptor ----
             constexpr int NB = (XR * XC * 8 + NTH - 1) / NTH;
             u32x4 vb[NB];
@@ -190,9 +378,9 @@ __global__ __launch_bounds__(512, 1) void resblock_chain_kernel(ChainParams p) {
                 const unsigned* f = p.flags + (nb_idx >= 0 ? nb_idx : tile_id);
                 unsigned spins = 0;
                 for (;;) {
-                    unsigned v = (unsigned)kb;
+                    unsigned v = (unsigned)(kb + fbase);
                     if (nb_idx >= 0) v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__all((int)(v >= (unsigned)kb))) break;
+                    if (__all((int)(v >= (unsigned)(kb + fbase)))) break;
                     if (++spins > CHAIN_SPIN_LIMIT) {          // wave-uniform
                         dead = true;
                         if (lane == 0) __hip_atomic_store(p.status, 0x100u + (unsigned)kb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -458,8 +646,8 @@ __global__ __launch_bounds__(512, 1) void resblock_chain_kernel(ChainParams p) {
                     ra[k] = P * 128 + ((q ^ c64_key(P)) << 4);
                     const int oy = y0 + trow, ox = x0 + colp;
                     const unsigned off = (oy < p.H && ox < p.W) ? (unsigned)oy * row_bytes + (unsigned)ox * 128u + 16u * q : OOB;   // (out of range: zeros)
-                    rpre[k][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, off, 0, 0));
-                    rpre[k][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, off + 64, 0, 0));
+                    rpre[k][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, off, 0, SC1));      // (sc1: this workgroup's
+                    rpre[k][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rres, off + 64, 0, SC1)); //  head link may have stored it)
                 }
             }
             // ================= phase 3: conv2 from T ==================================================
@@ -581,7 +769,7 @@ __global__ __launch_bounds__(512, 1) void resblock_chain_kernel(ChainParams p) {
         __builtin_amdgcn_s_barrier();                // A (also: the LDS tile holds the whole new centre)
         asm volatile("" ::: "memory");
         if (tid0 == 0 && kb + 1 < p.nblk)
-            __hip_atomic_store(p.flags + tile_id, (unsigned)(kb + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.flags + tile_id, (unsigned)(kb + 1 + fbase), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -689,11 +877,42 @@ static bool chain_wide_ok(const srmi_conv_args* a, int nprev, const srmi_conv_ar
     return true;
 }
 
+// the conv right in front of the first pair as the chain's head link: 9x9 from <= 3 channels to 64 (conv01 of
+// Generator.forward, P/srgan_model.py:29), any input form "k9c3_bf16" reads, dense 64-channel bf16 output = the first pair's x
+static bool chain_head_ok(const srmi_conv_args& h, const srmi_conv_args& first) {
+    const srmi_conv_desc& d = h.d;
+    if (!(h.flags & SRMI_CONV_FUSE_CHAIN) || (h.flags & SRMI_CONV_FUSE_NEXT) || h.x_copy || h.residual) return false;
+    if (!k9c3_supported(d) || select_kernel(d) != K_K9C3_BF16 || d.Cout != 64) return false;      // (packed-weight format = the kernel's)
+    if (d.N != first.d.N || d.H != first.d.H || d.W != first.d.W) return false;
+    if ((d.out_cstride && d.out_cstride != 64) || d.out_coffset) return false;
+    if (!h.x || !h.w || !h.y || !h.scale || !h.shift || h.y != first.x) return false;
+    if (d.act == SRMI_ACT_PRELU && !h.alpha) return false;
+    if (((uintptr_t)h.w | (uintptr_t)h.y) & 15) return false;
+    ConvGeom g;
+    if (conv_geom(d, &g)) return false;
+    return true;
+}
+
 // Convs of a[0 .. n) that can run as one chain starting at a[0]: L >= 2 ResBlock pairs (a[0], a[1]), (a[2], a[3]), ..., then
 // up to two single-conv tail links (*ntail: conv + residual, then the wide last link; either may be missing): 2 L + ntail,
 // or 0.  `fusable(a1, a2)` is api.hip's test for the fused ResBlock pair.
-int chain_run_length(const srmi_conv_args* a, int n, bool (*fusable)(const srmi_conv_args*, const srmi_conv_args*), int* npairs,
-                     int* kinds) {
+int chain_run_length(const srmi_conv_args* a0, int n0, bool (*fusable)(const srmi_conv_args*, const srmi_conv_args*), int* npairs,
+                     int* kinds, int* head) {
+    // an optional head link in front (*head = 1): the pairs then start at a0[1]
+    const bool hd = n0 > 1 && (a0[0].flags & SRMI_CONV_FUSE_CHAIN) && !(a0[0].flags & SRMI_CONV_FUSE_NEXT) && chain_head_ok(a0[0], a0[1]);
+    const srmi_conv_args* a = a0 + (hd ? 1 : 0);
+    const int n = n0 - (hd ? 1 : 0);
+    if (head) *head = hd ? 1 : 0;
+    if (n < 4) return 0;
+    {   // cheap rejections first (this runs for every flagged conv of every forward): the shape and the grid
+        const srmi_conv_desc& d = a[0].d;
+        if (d.W <= 64 || d.H < 12 || d.N <= 0) return 0;
+        const long long nb = (long long)d.N * ((d.W + 47) / 48) * ((d.H + 11) / 12);
+        std::lock_guard<std::mutex> lk(g_chain_mu);
+        ChainDev* cd = chain_dev();
+        if (!cd) return 0;
+        if (nb > cd->cus || nb * 4 > 4096) return 0;          // every workgroup must be resident at once (one per CU)
+    }
     int L = 0;
     while (L < CHAIN_MAX_BLOCKS - 2 && 2 * L + 1 < n) {
         const srmi_conv_args& a1 = a[2 * L];
@@ -708,24 +927,18 @@ int chain_run_length(const srmi_conv_args* a, int n, bool (*fusable)(const srmi_
         ++L;
     }
     if (L < 2) return 0;
-    const srmi_conv_desc& d = a[0].d;
-    const long long nb = (long long)d.N * ((d.W + 47) / 48) * ((d.H + 11) / 12);
-    {
-        std::lock_guard<std::mutex> lk(g_chain_mu);
-        ChainDev* cd = chain_dev();
-        if (!cd) return 0;
-        if (nb > cd->cus || nb * 4 > 4096) return 0;          // every workgroup must be resident at once (one per CU)
-    }
     int nc = 2 * L, nt = 0;
     int k[2] = {0, 0};
     if (nc < n && chain_tail_ok(a, nc, a[nc])) { k[nt++] = 1; ++nc; }
     if (nc < n && chain_wide_ok(a, nc, a[nc])) { k[nt++] = 2; ++nc; }
     if (npairs) *npairs = L;
     if (kinds) { kinds[0] = k[0]; kinds[1] = k[1]; }
-    return nc;
+    return nc + (hd ? 1 : 0);
 }
 
-int chain_launch(const srmi_conv_args* a, int npairs, const int* kinds, hipStream_t s) {
+// a0 = first conv of the chain (the head link if head != 0, else the first pair's first conv)
+int chain_launch(const srmi_conv_args* a0, int head, int npairs, const int* kinds, hipStream_t s) {
+    const srmi_conv_args* a = a0 + (head ? 1 : 0);
     const int L = npairs;
     const int ntail = (kinds[0] ? 1 : 0) + (kinds[1] ? 1 : 0);
     const srmi_conv_desc& d = a[0].d;
@@ -741,6 +954,19 @@ int chain_launch(const srmi_conv_args* a, int npairs, const int* kinds, hipStrea
     ChainParams p;
     memset(&p, 0, sizeof p);
     p.x = (const bf16_t*)a[0].x;
+    if (head) {
+        const srmi_conv_args& h = a0[0];
+        ConvGeom g;
+        int rc = conv_geom(h.d, &g);
+        if (rc) return rc;
+        p.head.on = 1;
+        p.head.x = h.x; p.head.w = (const bf16_t*)h.w;
+        p.head.scale = h.scale; p.head.shift = h.shift; p.head.alpha = h.alpha;
+        p.head.y = (bf16_t*)h.y;
+        p.head.Cin = h.d.Cin; p.head.in_cs = g.in_cs;
+        p.head.in_nchw = h.d.in_layout == SRMI_NCHW; p.head.in_bf16 = h.d.in_dtype == SRMI_BF16;
+        p.head.act = h.d.act; p.head.act_param = h.d.act_param; p.head.alpha_pc = h.d.alpha_per_channel;
+    }
     p.flags = cd->flags; p.status = cd->status_dev;
     p.N = d.N; p.H = d.H; p.W = d.W;
     p.tiles_x = (d.W + 47) / 48; p.tiles_y = (d.H + 11) / 12;

@@ -196,7 +196,7 @@ class GeneratorPlan:
         img = gen.conv01.body[0].in_channels
         # conv01 reads the caller's NCHW f32 tensor directly (no separate re-layout pass)
         skip = s.buf(N, H, W, nf)
-        s.add(gen.conv01, None, skip, N, H, W, in_layout=L.NCHW, in_dtype=L.F32)
+        s.add(gen.conv01, None, skip, N, H, W, in_layout=L.NCHW, in_dtype=L.F32, chain=True)     # (may be the chained trunk's head link)
         cur = skip
         tmp = s.buf(N, H, W, nf)
         ping = [s.buf(N, H, W, nf), s.buf(N, H, W, nf)]

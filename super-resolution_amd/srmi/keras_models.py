@@ -183,7 +183,7 @@ class KerasSRGANPlan(_Plan):
         s = _Seq(dev, compute)
         nf = m.n_feats
         first = s.buf(N, H, W, nf)
-        s.add((m.head, None, m.head_act), None, first, N, H, W, in_layout=L.NCHW, in_dtype=L.F32)
+        s.add((m.head, None, m.head_act), None, first, N, H, W, in_layout=L.NCHW, in_dtype=L.F32, chain=True)
         cur, tmp, ping = first, s.buf(N, H, W, nf), [s.buf(N, H, W, nf), s.buf(N, H, W, nf)]
         for i, blk in enumerate(m.blocks):
             out = ping[i & 1]

@@ -220,6 +220,74 @@ def test_chain_with_wide_last_link(case):
         assert torch.all(feat[:, ~border] == 4.0)
 
 
+@pytest.mark.parametrize("case", [
+    dict(N=16, H=96, W=96, nblk=16, nchw=True),       # cfg1's whole front: conv01 + trunk + conv02 (+ the up conv in the generator test)
+    dict(N=2, H=50, W=70, nblk=2, nchw=True),
+    dict(N=1, H=25, W=130, nblk=2, nchw=False, cin=2),
+    dict(N=3, H=13, W=65, nblk=3, nchw=False, bf16=True, cin=3),
+])
+def test_chain_with_head_conv(case):
+    """conv 9x9 from <= 3 image channels (conv01, P/srgan_model.py:29) as the chain's first link, conv + skip add as its
+    last: the skip tensor is written AND read back inside the one launch."""
+    lib = L.load()
+    N, H, W, nblk = case["N"], case["H"], case["W"], case["nblk"]
+    cin = case.get("cin", 3)
+    arr0, bufs, tmp, keep = _build(N, H, W, nblk, seed=41)
+    n = 2 * nblk + 2
+    arr = (L.ConvArgs * n)()
+    for i in range(2 * nblk):
+        C.memmove(C.byref(arr[i + 1]), C.byref(arr0[i]), C.sizeof(L.ConvArgs))
+    g = np.random.default_rng(14)
+    skip = keep[0]                                  # the pairs' input buffer becomes conv01's output
+    skip.fill_(1.5)
+    if case["nchw"]:
+        img = torch.from_numpy(g.uniform(0, 1, (N, cin, H, W)).astype(np.float32)).to(DEV)
+        lay, dt = L.NCHW, L.F32
+    else:
+        img = torch.from_numpy(g.uniform(0, 1, (N, H, W, cin)).astype(np.float32)).to(DEV)
+        lay, dt = L.NHWC, L.F32
+        if case.get("bf16"):
+            img, dt = img.bfloat16(), L.BF16
+    d0 = Fn.make_desc(N, H, W, cin, 64, 9, in_dtype=dt, out_dtype=L.BF16, res_dtype=L.BF16, in_layout=lay, compute=L.COMPUTE_BF16,
+                      act=L.ACT_PRELU)
+    assert L.kernel_name(d0) == "k9c3_bf16"
+    w0 = torch.from_numpy((g.standard_normal((64, cin, 9, 9)) / 9.0).astype(np.float32)).to(DEV)
+    wp0 = Fn.pack_weights(d0, w0)
+    sc0 = torch.ones(64, device=DEV)
+    sh0 = torch.from_numpy(g.uniform(-0.2, 0.2, 64).astype(np.float32)).to(DEV)
+    al0 = torch.tensor([0.25], dtype=torch.float32, device=DEV)
+    Fn.fill_args(arr[0], d0, img, wp0, sc0, sh0, al0, None, skip)
+    d = Fn.make_desc(N, H, W, 64, 64, 3, in_dtype=L.BF16, out_dtype=L.BF16, res_dtype=L.BF16, compute=L.COMPUTE_BF16, act=L.ACT_NONE)
+    w = torch.from_numpy((g.standard_normal((64, 64, 3, 3)) / 30.0).astype(np.float32)).to(DEV)
+    wp = Fn.pack_weights(d, w)
+    sc = torch.from_numpy(g.uniform(0.5, 1.2, 64).astype(np.float32)).to(DEV)
+    sh = torch.from_numpy(g.uniform(-0.2, 0.2, 64).astype(np.float32)).to(DEV)
+    out = torch.full((N, H, W, 64), 7.0, dtype=torch.bfloat16, device=DEV)
+    Fn.fill_args(arr[n - 1], d, bufs[-1], wp, sc, sh, None, skip, out)
+
+    def run(chain):
+        arr[0].flags = L.CONV_FUSE_CHAIN if chain else 0
+        for i in range(1, n - 1, 2):
+            arr[i].flags = L.CONV_FUSE_NEXT | ((L.CONV_FUSE_CHAIN | L.CONV_Y_TRANSIENT) if chain else 0)
+        arr[n - 1].flags = L.CONV_FUSE_CHAIN if chain else 0
+        L.check(lib.srmi_conv2d_fwd_seq(arr, n, Fn.stream_ptr()))
+        torch.cuda.synchronize()
+
+    run(False)
+    ref, ref_skip = out.clone(), skip.clone()
+    out.fill_(-2.0)
+    skip.fill_(0.5)
+    arr[0].flags = L.CONV_FUSE_CHAIN
+    for i in range(1, n - 1, 2):
+        arr[i].flags = L.CONV_FUSE_NEXT | L.CONV_FUSE_CHAIN
+    arr[n - 1].flags = L.CONV_FUSE_CHAIN
+    assert lib.srmi_conv2d_chain_length(arr, n) == n
+    run(True)
+    assert lib.srmi_chain_status() == 0
+    assert torch.equal(ref_skip, skip), int((ref_skip != skip).sum())
+    assert torch.equal(ref, out), int((ref != out).sum())
+
+
 def test_chain_refused_shapes_fall_back():
     """More workgroups than CUs, narrow images, a foreign residual: no chain, same results through single launches."""
     lib = L.load()
@@ -271,7 +339,7 @@ def test_generator_chain_switch():
     with torch.no_grad():
         sr1, f1 = gen(x)
         plan = gen._plans.get(gen, 2, 48, 96, 1)
-        assert any(lbl == "resblock_chain_bf16" and cnt == 12 for (lbl, i0, cnt) in plan.launches), plan.launches
+        assert any(lbl == "resblock_chain_bf16" and cnt == 13 for (lbl, i0, cnt) in plan.launches), plan.launches
         engine.set_fuse_chain(False)
         try:
             engine.invalidate(gen)
