@@ -23,6 +23,9 @@
 namespace srmi {
 
 constexpr int CHAIN_MAX_BLOCKS = 24;
+constexpr int CHAIN_FLAG_WORDS = 1024;                  // 4 KiB per device: tile flags + the two words below
+constexpr int CHAIN_EPOCH = CHAIN_FLAG_WORDS - 2, CHAIN_DONE = CHAIN_FLAG_WORDS - 1;
+constexpr int CHAIN_MAX_TILES = CHAIN_FLAG_WORDS - 64;
 constexpr unsigned CHAIN_SPIN_LIMIT = 1u << 19;   // polls of ~1-2 us (load round trip + s_sleep) before a workgroup gives up: ~1 s
 
 struct ChainBlk {      // what changes from block to block
@@ -51,7 +54,8 @@ struct ChainHead {     // optional first link: the 9x9 conv from <= 3 image chan
 struct ChainParams {
     ChainHead head;
     const bf16_t* x;       // input of block 0 (no head link)
-    unsigned* flags;       // [tiles] blocks published by each tile; zeroed on the stream before the launch
+    unsigned* flags;       // [tiles] links published by each tile, counted from 64 x (launch epoch): never reset.  flags[CHAIN_EPOCH]
+                           // = the epoch, flags[CHAIN_DONE] = workgroups of the running launch that have finished
     unsigned* status;      // sticky give-up word (host-mapped)
     int N, H, W, tiles_x, tiles_y, nblk;
     ChainBlk blk[CHAIN_MAX_BLOCKS];
@@ -98,6 +102,10 @@ __global__ __launch_bounds__(512, 1) void resblock_chain_kernel(ChainParams p) {
         if (nty >= 0 && nty < p.tiles_y && ntx >= 0 && ntx < p.tiles_x) nb_idx = (n * p.tiles_y + nty) * p.tiles_x + ntx;
     }
     bool dead = false;      // this workgroup gave up waiting once: it waits no more (wave-uniform, wave 0 only)
+    // Flag values count from 64 x epoch, and the epoch lives in device memory: the workgroup that finishes last raises it
+    // for the next launch (launches on one device are ordered, chain_launch sees to it), so no word has to be zeroed per
+    // launch and nothing depends on a host-side launch count (a captured graph replays correctly).
+    const unsigned fepoch = __hip_atomic_load(p.flags + CHAIN_EPOCH, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) << 6;
 
     const unsigned img_bytes = (unsigned)p.H * p.W * 128u;
     const unsigned row_bytes = (unsigned)p.W * 128u;
@@ -312,7 +320,7 @@ __global__ __launch_bounds__(512, 1) void resblock_chain_kernel(ChainParams p) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        if (tid0 == 0) __hip_atomic_store(p.flags + tile_id, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid0 == 0) __hip_atomic_store(p.flags + tile_id, fepoch + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 
     // the per-block table is read from the kernel-argument segment by scalar loads (indexing the by-value struct with the
@@ -378,9 +386,9 @@ __global__ __launch_bounds__(512, 1) void resblock_chain_kernel(ChainParams p) {
                 const unsigned* f = p.flags + (nb_idx >= 0 ? nb_idx : tile_id);
                 unsigned spins = 0;
                 for (;;) {
-                    unsigned v = (unsigned)(kb + fbase);
+                    unsigned v = fepoch + (unsigned)(kb + fbase);
                     if (nb_idx >= 0) v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__all((int)(v >= (unsigned)(kb + fbase)))) break;
+                    if (__all((int)(v - (fepoch + (unsigned)(kb + fbase))) >= 0)) break;
                     if (++spins > CHAIN_SPIN_LIMIT) {          // wave-uniform
                         dead = true;
                         if (lane == 0) __hip_atomic_store(p.status, 0x100u + (unsigned)kb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -769,7 +777,15 @@ __global__ __launch_bounds__(512, 1) void resblock_chain_kernel(ChainParams p) {
         __builtin_amdgcn_s_barrier();                // A (also: the LDS tile holds the whole new centre)
         asm volatile("" ::: "memory");
         if (tid0 == 0 && kb + 1 < p.nblk)
-            __hip_atomic_store(p.flags + tile_id, (unsigned)(kb + 1 + fbase), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.flags + tile_id, fepoch + (unsigned)(kb + 1 + fbase), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    // ---- the last workgroup to finish opens the next epoch ----
+    if (tid0 == 0) {
+        const unsigned old = __hip_atomic_fetch_add(p.flags + CHAIN_DONE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old == gridDim.x - 1) {
+            __hip_atomic_store(p.flags + CHAIN_DONE, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(p.flags + CHAIN_EPOCH, (fepoch >> 6) + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
 }
 
@@ -800,7 +816,8 @@ static ChainDev* chain_dev() {       // call with g_chain_mu held
         void* std_ = nullptr;
         if (hip_check(hipHostGetDevicePointer(&std_, st, 0), "hipHostGetDevicePointer")) return nullptr;
         void* fl = nullptr;
-        if (hip_check(hipMalloc(&fl, 4096), "hipMalloc(chain flags)")) return nullptr;
+        if (hip_check(hipMalloc(&fl, CHAIN_FLAG_WORDS * 4), "hipMalloc(chain flags)")) return nullptr;
+        if (hip_check(hipMemset(fl, 0, CHAIN_FLAG_WORDS * 4), "hipMemset(chain flags)")) return nullptr;     // once: epoch 0, nothing published
         d.status_host = (unsigned*)st; d.status_dev = (unsigned*)std_;
         d.cus = prop.multiProcessorCount;
         d.flags = (unsigned*)fl;
@@ -911,7 +928,7 @@ int chain_run_length(const srmi_conv_args* a0, int n0, bool (*fusable)(const srm
         std::lock_guard<std::mutex> lk(g_chain_mu);
         ChainDev* cd = chain_dev();
         if (!cd) return 0;
-        if (nb > cd->cus || nb * 4 > 4096) return 0;          // every workgroup must be resident at once (one per CU)
+        if (nb > cd->cus || nb > CHAIN_MAX_TILES) return 0;   // every workgroup must be resident at once (one per CU)
     }
     int L = 0;
     while (L < CHAIN_MAX_BLOCKS - 2 && 2 * L + 1 < n) {
@@ -1009,7 +1026,6 @@ int chain_launch(const srmi_conv_args* a0, int head, int npairs, const int* kind
         (void)hipStreamSynchronize(cd->last_stream);      // (a destroyed stream has drained: errors are not ours)
         (void)hipGetLastError();
     }
-    if (hip_check(hipMemsetAsync(cd->flags, 0, ((size_t)nb * 4 + 15) & ~(size_t)15, s), "hipMemsetAsync(chain flags)")) return SRMI_EHIP;
     hipLaunchKernelGGL(resblock_chain_kernel, dim3(nb), dim3(512), 0, s, p);
     int rc = hip_check(hipGetLastError(), "resblock_chain_kernel");
     if (rc) return rc;
