@@ -424,6 +424,14 @@ def main():
             if label in fam:
                 f_fam += fl; t_fam += kms[u] * 1e-3
         achieved = flops / t_dom / 1e12
+        # compulsory HBM bytes of one launch of the dominant kernel: the tensor it reads and the tensor(s) it writes
+        algo_bytes = 2 * BATCH * LR_H * LR_W * 64 * 2            # a fused ResBlock: 64-channel bf16 in and out
+        for (label, i, cnt) in units:
+            if label == "resblock_chain_bf16":                   # image in; `feat` (NCHW f32) and the last link's tensor out
+                d0, d1 = plan.args[i].d, plan.args[i + cnt - 1].d
+                algo_bytes = d0.N * d0.H * d0.W * d0.Cin * (2 if d0.in_dtype == 1 else 4) + d1.N * d1.H * d1.W * d1.Cout * 2
+                if plan.feat_idx is not None and i <= plan.feat_idx < i + cnt:
+                    algo_bytes += plan.N * plan.nf * plan.H * plan.W * 4
         layers = {k: {"launches": v[0], "ms": round(v[1], 4), "tflops": round(v[2] / (v[1] * 1e-3) / 1e12, 1)}
                   for k, v in per_layer.items()}
         trace_us = None      # average duration of the dominant kernel in the committed kernel trace (profiles/)
@@ -454,10 +462,9 @@ def main():
                     "kernel_trace_avg_us_from_committed_profile": trace_us,
                     "frac_by_committed_kernel_trace": round(flops / n_dom / (trace_us * 1e-6) / 1e12 / peak, 4) if trace_us else None,
                     "flops_per_launch": flops / n_dom,
-                    # compulsory HBM bytes of one launch: its input and its output tensor (16 x 96 x 96 x 64 bf16 each) - for
-                    # the chained trunk that is the whole chain's input and last output (what the blocks hand each other
-                    # between is traffic the chain could keep on chip: the PMC figure shows how much of it still goes out)
-                    "algorithmic_bytes_per_launch": 2 * BATCH * LR_H * LR_W * 64 * 2,
+                    # (for the chained trunk: what the links hand each other - two-pixel halo strips, write-through - is traffic
+                    #  beyond these bytes: the PMC figure shows it)
+                    "algorithmic_bytes_per_launch": algo_bytes,
                     "mfma_family_tflops": round(f_fam / t_fam / 1e12, 2),
                     "whole_step_frac": round(value / world * 1e6 * FLOP_PER_OUT_PIXEL / 1e12 / peak, 4),
                     "sum_kernel_ms": round(float(kms.sum()), 4), "layers": layers,

@@ -388,7 +388,9 @@ __global__ __launch_bounds__(512, 1) void resblock_chain_kernel(ChainParams p) {
                 for (;;) {
                     unsigned v = fepoch + (unsigned)(kb + fbase);
                     if (nb_idx >= 0) v = __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if (__all((int)(v - (fepoch + (unsigned)(kb + fbase))) >= 0)) break;
+                    // ready = published in THIS epoch, at least kb + fbase links (a word left over from another epoch - a tile
+                    // that earlier, smaller grids did not use - never matches)
+                    if (__all((int)((v ^ fepoch) < 64u && (v & 63u) >= (unsigned)(kb + fbase)))) break;
                     if (++spins > CHAIN_SPIN_LIMIT) {          // wave-uniform
                         dead = true;
                         if (lane == 0) __hip_atomic_store(p.status, 0x100u + (unsigned)kb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

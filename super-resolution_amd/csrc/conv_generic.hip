@@ -169,7 +169,8 @@ __global__ void generic_pack_dgrad_kernel(const float* __restrict__ w, float* __
 bool dgrad_subpixel(const srmi_conv_desc& d) {
     if (dbg_flags() & (1 << 14)) return false;
     return d.stride == 2 && d.kh == 3 && d.kw == 3 && d.pad == 1 && d.H % 2 == 0 && d.W % 2 == 0 && d.H > 0 && d.W > 0 &&
-           d.Cin % 32 == 0 && (long long)d.N * d.H * d.W < 0x7fffffffLL;      // (lean sub-pixel epilogue: whole 32-channel tiles)
+           d.Cin % 32 == 0;      // (lean sub-pixel epilogue: whole 32-channel tiles).  Shape of the WEIGHT and stride / pad / H, W
+                                 // parity only - never N: the packed operand format follows this predicate and is cached per weight
 }
 
 // its operand: OIHW f32 -> [tap (a, b)][Cout_pad8 (contracted)][(py, px, ci) padded to 32 (produced)]
@@ -497,7 +498,10 @@ int generic_dgrad_launch(const srmi_conv_desc& d, const ConvGeom& g, const float
     p.partial = (float*)ws;
     p.partial_stride = ws ? ws_bytes / sizeof(float) : 0;
     const long long M = (dgrad_subpixel(d) || dgrad_fullmap(d)) ? (long long)d.N * g.Ho * g.Wo : (long long)d.N * d.H * d.W;
-    if (M > 0x7fffffffLL) { set_error("dgrad: N*H*W = %lld exceeds int32", M); return SRMI_EINVAL; }
+    if (M > 0x7fffffffLL || (long long)d.N * d.H * d.W > 0x7fffffffLL) {
+        set_error("dgrad: N*H*W = %lld exceeds int32", (long long)d.N * d.H * d.W);
+        return SRMI_EINVAL;
+    }
     p.M = (int)M;
     if (p.M == 0) return SRMI_OK;
     return generic_run(p);
