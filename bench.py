@@ -46,6 +46,7 @@ import torch
 PEAK_BF16_TFLOPS = 2500.0     # MI355X dense bf16 MFMA (MI355X_MICROARCH.md, chip-level parameters)
 PEAK_F32_MFMA_TFLOPS = 157.3  # exact-f32 MFMA
 BATCH, LR_H, LR_W, NUM_BLOCK = 16, 96, 96, 16
+WARMUP_MIN_S = 0.3              # untimed warm-up runs at least this long (clock ramp after idle), whatever --warmup says
 FLOP_PER_OUT_PIXEL = 249_624  # SURVEY App. A / BASELINE.md section 4 (conv MACs x 2 only)
 PROFILE_TAG = "r3"            # profiles/<tag>_bench_kernel_stats.csv, <tag>_pmc_traffic.json: the committed rocprofv3 runs
 
@@ -284,6 +285,14 @@ def run_cfg5(args, dev, dist, rank, world):
     frame = torch.empty((1, 3, 540, 960)).uniform_(-1.0, 1.0, generator=torch.Generator().manual_seed(1)).to(dev)
     out = torch.zeros((1, 3, 2160, 3840), dtype=torch.float32, device=dev)
     steps = max(args.steps, 32)                      # a stream of >= 32 frames
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_variants as V
+    kw, how = V.cfg5_tiling(dev)
+    from srmi.tiling import plan_tiles_equal
+    nt = len(plan_tiles_equal(540, 960, kw["grid"][0], kw["grid"][1], 8))
+
+    def frame_rank(f):        # the stream's (frame, tile) units go round-robin to the ranks: tile t of frame f -> (f nt + t) % world
+        return (rank - f * nt) % world
 
     def barrier():
         torch.cuda.synchronize()
@@ -291,12 +300,13 @@ def run_cfg5(args, dev, dist, rank, world):
             dist.barrier()
         torch.cuda.synchronize()
     with torch.no_grad():
-        for _ in range(args.warmup):
-            sr_tiled(gen, frame, halo=8, grid=(2, 4), rank=rank, world=world, out=out)
+        for f in range(args.warmup):
+            sr_tiled(gen, frame, halo=8, rank=frame_rank(f), world=world, out=out, **kw)
         barrier()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            _, ntiles = sr_tiled(gen, frame, halo=8, grid=(2, 4), rank=rank, world=world, out=out)
+        ntiles = 0
+        for f in range(steps):
+            ntiles += sr_tiled(gen, frame, halo=8, rank=frame_rank(f), world=world, out=out, **kw)[1]
         barrier()
         elapsed = time.perf_counter() - t0
     elapsed = max_over_ranks(elapsed, dist, dev)
@@ -309,10 +319,9 @@ def run_cfg5(args, dev, dist, rank, world):
             "n_gpus": world, "steps": steps, "warmup": args.warmup, "ms_per_step": round(elapsed / steps * 1e3, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
             "dtype": "bf16" if args.compute == "bf16" else "f32", "data": "synthetic",
-            "config": {"workload": "cfg5: tiled SRResNet x4 inference, 960x540 -> 3840x2160 frames, 2 x 4 LR tiles per frame of "
-                                   "equal extended shape 278x252 (8 px halo) dealt round-robin to the ranks, no collective; "
-                                   "useful pixels only",
-                       "tiles_per_frame": 8, "tiles_rank0": ntiles, "parallelism": f"tile-sharded x{world}, no collective"},
+            "config": {"workload": "cfg5: tiled SRResNet x4 inference, 960x540 -> 3840x2160 frames, 8 px halo, " + how +
+                                   "; the stream's (frame, tile) units dealt round-robin to the ranks, no collective; useful pixels only",
+                       "tiles_per_frame": nt, "tiles_rank0": ntiles, "parallelism": f"tile-sharded x{world}, no collective"},
             "roofline": {"bound": "mfma", "achieved": round(tf, 2), "peak": PEAK_BF16_TFLOPS * world, "unit": "TFLOP/s",
                          "frac": round(tf / (PEAK_BF16_TFLOPS * world), 4), "traffic": None,
                          "note": "whole-job useful FLOPs (249,624 per output pixel) / time; the per-kernel roofline is on the cfg1 line"}}
@@ -384,8 +393,16 @@ def main():
         torch.cuda.synchronize()
 
     with torch.no_grad():
-        for _ in range(args.warmup):
+        # W untimed warm-up steps - and, still untimed, further ones until WARMUP_MIN_S of wall time have passed: the first
+        # tens of milliseconds after an idle period run at ramping clocks (20 steps timed right behind 5 warm-up steps read
+        # 13 % slower than the same 20 steps behind a 0.3 s warm-up; 200+ timed steps do not care).  The count is reported.
+        tw0 = time.perf_counter()
+        warm_run = 0
+        while warm_run < args.warmup or time.perf_counter() - tw0 < WARMUP_MIN_S:
             gen(x)
+            warm_run += 1
+            if warm_run % 16 == 0:
+                torch.cuda.synchronize()
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.steps):
@@ -476,7 +493,7 @@ def main():
                               "kernel_trace_avg_us_from_committed_profile are read from profiles/ (see traffic_source)"}
         result = {
             "metric": "x4 SR output megapixels/sec (whole node)", "value": round(value, 2), "unit": "MP/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 4),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "warmup_steps_run": warm_run, "ms_per_step": round(ms, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16" if args.compute == "bf16" else "f32", "data": "synthetic",
             "config": {"workload": "SRResNet x4 generator forward (16 res blocks, 64ch, 2x PixelShuffle), "

@@ -69,8 +69,23 @@ def plan_tiles_equal(H, W, ny, nx, halo):
     return tiles
 
 
+def strips_for_chain(H, W, halo, cus, th=12, tw=48):
+    """Fewest horizontal strips ny such that ONE extended strip (all W columns) is at most `cus` tiles of th x tw pixels:
+    the shape for which the generator's front runs as one persistent chained launch per strip (every workgroup of the
+    chain must be resident at once: include/srmi.h SRMI_CONV_FUSE_CHAIN).  960x540 with an 8-pixel halo on 256 CUs: 5
+    strips of 121 rows = 11 x 20 = 220 workgroups each.  None if even a th-row strip is too wide."""
+    tx = -(-W // tw)
+    if tx > cus:
+        return None
+    for ny in range(1, H + 1):
+        ext = max(t[5] - t[4] for t in plan_tiles_equal(H, W, ny, 1, halo))
+        if -(-ext // th) * tx <= cus:
+            return ny
+    return None
+
+
 @torch.no_grad()
-def sr_tiled(fn, lr, tile=(270, 240), halo=8, scale=4, rank=0, world=1, out=None, grid=None):
+def sr_tiled(fn, lr, tile=(270, 240), halo=8, scale=4, rank=0, world=1, out=None, grid=None, max_batch=None):
     """Run `fn(lr_tiles) -> (sr, feat)` (a Generator) over this rank's tiles of `lr` (N,C,H,W).
 
     Returns (out, n_tiles): `out` is (N,C,scale*H,scale*W) with this rank's core regions filled (zeros
@@ -84,13 +99,17 @@ def sr_tiled(fn, lr, tile=(270, 240), halo=8, scale=4, rank=0, world=1, out=None
     groups = defaultdict(list)
     for t in tiles:
         groups[(t[5] - t[4], t[7] - t[6])].append(t)          # equal extended shapes share one launch sequence
-    for (_eh, _ew), ts in groups.items():
-        batch = torch.cat([lr[:, :, t[4]:t[5], t[6]:t[7]] for t in ts], dim=0).contiguous()
-        sr = fn(batch)[0]
-        for i, (y0, y1, x0, x1, ey0, _ey1, ex0, _ex1) in enumerate(ts):
-            oy, ox = scale * (y0 - ey0), scale * (x0 - ex0)
-            out[:, :, scale * y0:scale * y1, scale * x0:scale * x1] = \
-                sr[i * N:(i + 1) * N, :, oy:oy + scale * (y1 - y0), ox:ox + scale * (x1 - x0)]
+    for (_eh, _ew), group in groups.items():
+        # max_batch: at most that many tiles per call of fn (1 with strips_for_chain's strips: one chained launch each)
+        step = len(group) if not max_batch else max(1, int(max_batch))
+        for g0 in range(0, len(group), step):
+            ts = group[g0:g0 + step]
+            batch = torch.cat([lr[:, :, t[4]:t[5], t[6]:t[7]] for t in ts], dim=0).contiguous()
+            sr = fn(batch)[0]
+            for i, (y0, y1, x0, x1, ey0, _ey1, ex0, _ex1) in enumerate(ts):
+                oy, ox = scale * (y0 - ey0), scale * (x0 - ex0)
+                out[:, :, scale * y0:scale * y1, scale * x0:scale * x1] = \
+                    sr[i * N:(i + 1) * N, :, oy:oy + scale * (y1 - y0), ox:ox + scale * (x1 - x0)]
     return out, len(tiles)
 
 

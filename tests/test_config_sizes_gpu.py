@@ -87,6 +87,40 @@ def test_cfg5_equal_extended_tiles_match_generator_on_crops():
                                stitched[:, :, 4 * y0:4 * y1, 4 * x0:4 * x1]), (y0, x0)
 
 
+def test_cfg5_chain_strips_match_launch_per_block_on_crops():
+    """cfg5 as bench.py times it on a GPU whose CUs hold one strip's tiles: horizontal strips (tiling.strips_for_chain), one
+    call per strip, each call's front ONE chained launch - against `Generator` on the same crops with the chain switched
+    off (one launch per ResBlock): bit-identical."""
+    from importlib import import_module
+    engine = import_module("super-resolution_amd.srmi.engine")
+    cus = torch.cuda.get_device_properties(DEV).multi_processor_count
+    ny = tiling.strips_for_chain(540, 960, 8, cus)
+    if ny is None or ny > 8:
+        pytest.skip("no strip of this frame fits the GPU's CUs")
+    gen = Generator(num_block=16)
+    gen.load_state_dict(O.to_torch(W.generator_weights(seed=0, num_block=16)))
+    gen = gen.to(DEV).eval().set_compute("bf16")
+    x = torch.from_numpy(W.lr_input((1, 3, 540, 960), seed=77)).to(DEV)
+    plan = tiling.plan_tiles_equal(540, 960, ny, 1, 8)
+    with torch.no_grad():
+        stitched, n = tiling.sr_tiled(gen, x, halo=8, grid=(ny, 1), max_batch=1)
+        assert n == ny and stitched.shape == (1, 3, 2160, 3840)
+        t = plan[0]
+        p0 = gen._plans.get(gen, 1, t[5] - t[4], t[7] - t[6], 1)
+        assert any(lbl == "resblock_chain_bf16" for (lbl, i0, cnt) in p0.launches), p0.launches
+        engine.set_fuse_chain(False)
+        try:
+            engine.invalidate(gen)
+            for (y0, y1, x0, x1, ey0, ey1, ex0, ex1) in plan:
+                sr, _ = gen(x[:, :, ey0:ey1, ex0:ex1].contiguous())
+                oy, ox = 4 * (y0 - ey0), 4 * (x0 - ex0)
+                assert torch.equal(sr[:, :, oy:oy + 4 * (y1 - y0), ox:ox + 4 * (x1 - x0)],
+                                   stitched[:, :, 4 * y0:4 * y1, 4 * x0:4 * x1]), (y0, x0)
+        finally:
+            engine.set_fuse_chain(True)
+            engine.invalidate(gen)
+
+
 @pytest.mark.parametrize("compute", ["bf16", "fp32"])
 def test_cfg5_tiles_match_generator_on_crops(compute):
     """BASELINE config 5: one 960x540 LR frame, 4 x 2 core tiles of 240 x 270 with an 8-px halo, 16-block generator.

@@ -99,3 +99,23 @@ def test_single_process_tiling_matches_whole_frame():
     out, n = tiling.sr_tiled(_stub_generator, lr, tile=(7, 9), halo=2)
     assert n == 12 and torch.equal(out, _stub_generator(lr)[0])
     assert tiling.max_over_ranks(0.25) == 0.25
+
+
+def test_strips_for_chain_and_max_batch():
+    """cfg5 on 256 CUs: five strips of 121 x 960 (11 x 20 = 220 tiles of 12 x 48 each); max_batch = 1 runs them one call
+    per strip and stitches the same frame as one batch."""
+    assert tiling.strips_for_chain(540, 960, 8, 256) == 5
+    assert {t[5] - t[4] for t in tiling.plan_tiles_equal(540, 960, 5, 1, 8)} <= {120, 121}
+    assert tiling.strips_for_chain(540, 960, 8, 304) == 4
+    assert tiling.strips_for_chain(100, 100000, 8, 256) is None
+    assert tiling.strips_for_chain(96, 96, 8, 256) == 1
+    lr = torch.rand(1, 3, 50, 40)
+    calls = []
+
+    def fn(b):
+        calls.append(b.shape[0])
+        return _stub_generator(b)
+    a, n = tiling.sr_tiled(fn, lr, halo=2, grid=(5, 1), max_batch=1)
+    assert n == 5 and calls == [1] * 5
+    b, _ = tiling.sr_tiled(_stub_generator, lr, halo=2, grid=(5, 1))
+    assert torch.equal(a, b)

@@ -86,8 +86,20 @@ def cfg2(steps=10, warmup=3, compute="bf16", per_layer=True):
                 steps, warmup, compute, per_layer=per_layer)]
 
 
+def cfg5_tiling(dev="cuda:0", H=540, W=960, halo=8):
+    """How a 960x540 frame is cut: horizontal strips that each fit the GPU as ONE chained launch of the generator's front
+    (srmi.tiling.strips_for_chain: 5 strips of 121 x 960 on 256 CUs, one call per strip), else 2 x 4 tiles as one batch."""
+    from srmi import engine
+    from srmi.tiling import strips_for_chain
+    cus = torch.cuda.get_device_properties(dev).multi_processor_count
+    ny = strips_for_chain(H, W, halo, cus) if engine._FUSE_CHAIN else None
+    if ny is not None and ny <= 8:
+        return dict(grid=(ny, 1), max_batch=1), f"{ny} strips of equal extended shape (one chained launch of the front each)"
+    return dict(grid=(2, 4)), "2 x 4 tiles of equal extended shape 278x252, one batch of eight"
+
+
 def cfg5(steps=10, warmup=3, compute="bf16", gen=None):
-    """BASELINE config 5 on ONE GPU: one 960x540 frame -> 3840x2160 through 2 x 4 LR tiles of equal extended shape (278x252 with the 8 px halo): one batch of eight."""
+    """BASELINE config 5 on ONE GPU: one 960x540 frame -> 3840x2160 with the 8 px halo (tiling: cfg5_tiling)."""
     from srmi.srgan_model import Generator
     from srmi.tiling import sr_tiled
     from bench import synthetic_state
@@ -96,17 +108,18 @@ def cfg5(steps=10, warmup=3, compute="bf16", gen=None):
         gen.load_state_dict(synthetic_state(gen, 0))
         gen = gen.to("cuda:0").eval().set_compute(compute)
     frame = (torch.rand(1, 3, 540, 960, generator=torch.Generator().manual_seed(0)) * 2 - 1).to("cuda:0")
+    kw, how = cfg5_tiling()
     with torch.no_grad():
         for _ in range(warmup):
-            sr_tiled(gen, frame, halo=8, grid=(2, 4))
+            sr_tiled(gen, frame, halo=8, **kw)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
-            out, ntiles = sr_tiled(gen, frame, halo=8, grid=(2, 4))
+            out, ntiles = sr_tiled(gen, frame, halo=8, **kw)
         torch.cuda.synchronize()
         el = (time.perf_counter() - t0) / steps
     flop = 8.2944e6 * 249_624          # useful output pixels only (halo recompute not counted)
-    return {"workload": "cfg5 SRResNet x4, 960x540 -> 3840x2160, 2 x 4 tiles of equal extended shape 278x252 (8 px halo), 1 GPU",
+    return {"workload": f"cfg5 SRResNet x4, 960x540 -> 3840x2160, 8 px halo, {how}, 1 GPU",
             "compute": compute, "ms_per_frame": round(el * 1e3, 3), "out_mp_per_s": round(8.2944 / el, 1),
             "tflops": round(flop / el / 1e12, 1), "frac_of_bf16_peak": round(flop / el / 2.5e15, 4), "tiles": ntiles}
 
