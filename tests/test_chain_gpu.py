@@ -352,3 +352,39 @@ def test_generator_chain_switch():
     torch.cuda.synchronize()
     assert torch.equal(sr1, sr2) and torch.equal(f1, f2)
     assert L.load().srmi_chain_status() == 0
+
+
+def test_chain_soak_and_uneven_load():
+    """Hand-offs under repetition and under uneven load (MI355X_MICROARCH.md: 'test every hand-off under UNEVEN load,
+    consumer L1-warm, checking every word'): 150 chained launches back to back over two alternating inputs, the second
+    half of them while another stream keeps part of the chip busy with a memory-streaming kernel (so some of the chain's
+    workgroups start late and their neighbours have to wait) - every launch's final tensor is compared bit for bit with
+    the launch-per-block result of its input."""
+    lib = L.load()
+    N, H, W, nblk = 16, 96, 96, 6
+    arr, bufs, tmp, keep = _build(N, H, W, nblk, seed=77)
+    n = 2 * nblk
+    xa = keep[0]
+    xb = torch.from_numpy(np.random.default_rng(3).uniform(-1, 1, (N, H, W, 64)).astype(np.float32)).bfloat16().to(DEV)
+    xs = [xa.clone(), xb]
+    refs = []
+    for xin in xs:
+        xa.copy_(xin)
+        _run(arr, n, L.CONV_FUSE_NEXT)
+        refs.append(bufs[-1].clone())
+    side = torch.cuda.Stream()
+    big = torch.empty(64 << 20, dtype=torch.float32, device=DEV)
+    outs = []
+    for it in range(150):
+        xa.copy_(xs[it & 1])
+        if it >= 75:
+            with torch.cuda.stream(side):
+                big.add_(1.0)                         # 512 MB of traffic on the other stream, concurrently
+        for i in range(0, n, 2):
+            arr[i].flags = L.CONV_FUSE_NEXT | L.CONV_FUSE_CHAIN | L.CONV_Y_TRANSIENT
+        L.check(lib.srmi_conv2d_fwd_seq(arr, n, Fn.stream_ptr()))
+        outs.append(bufs[-1].clone())
+    torch.cuda.synchronize()
+    assert lib.srmi_chain_status() == 0, lib.srmi_last_error()
+    bad = [it for it, o in enumerate(outs) if not torch.equal(o, refs[it & 1])]
+    assert not bad, bad[:10]
