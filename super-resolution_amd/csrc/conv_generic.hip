@@ -316,6 +316,10 @@ int generic_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, h
 static int generic_run(const struct GenericParams& p);
 
 
+// vector-ALU kernels for convs with <= 4 channels on one side (conv_thin_f32.hip): 0 = not such a conv
+int thinf_kind(const GenericParams& p);
+int thinf_launch(const GenericParams& p);
+
 // LDS-tiled kernel for NHWC f32 inputs (conv_f32_tiled.hip); this file's kernel serves the other input layouts / dtypes
 bool f32t_supported(const GenericParams& p);
 int f32t_ksplit(const GenericParams& p);
@@ -358,6 +362,7 @@ static int generic_ksplit(const GenericParams& p) {
 static void generic_fill(GenericParams& p, const srmi_conv_args& a, const ConvGeom& g);
 
 static int pick_ksplit(const GenericParams& p) {
+    if (thinf_kind(p)) return 1;
     if (p.b3 == 2) return 1;
     if (p.b3) return b3_ksplit(p);
     return f32t_supported(p) ? f32t_ksplit(p) : generic_ksplit(p);
@@ -420,6 +425,7 @@ const char* generic_kernel_label(const srmi_conv_desc& d, const ConvGeom& g) {
     a.d = d;
     GenericParams p;
     generic_fill(p, a, g);
+    if (thinf_kind(p)) return "thin_f32";
     if (p.b3 == 2) return "b3h_f32";
     if (p.b3) return "b3_f32";
     return f32t_supported(p) ? "f32t" : "generic_f32";
@@ -435,6 +441,10 @@ static int generic_run(const GenericParams& p0) {
     // scale and a dense f32 output, which is what the training path asks for, and a workspace: the slices are
     // stored there and added in slice order, so the result is the same bits on every run.  There are NO float
     // atomics in this file: without a (large enough) workspace the conv simply does not split.
+    if (thinf_kind(p)) {          // <= 4 channels on one side: HBM-bound, one pass on the vector ALU
+        p.ksplit = 1;
+        return thinf_launch(p);
+    }
     const bool tiled = f32t_supported(p);
     p.ksplit = pick_ksplit(p);
     const size_t out_elems = (size_t)p.N * p.Cf * p.Hf * p.Wf;

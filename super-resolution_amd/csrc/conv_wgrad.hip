@@ -402,8 +402,15 @@ static int wgrad_plan(const srmi_conv_desc& d, const ConvGeom& g, bool allow_spl
     return SRMI_OK;
 }
 
+// <= 4 channels on one side (conv_thin_f32.hip)
+bool thinf_wgrad_ok(const srmi_conv_desc& d, const ConvGeom& g);
+size_t thinf_wgrad_workspace_bytes(const srmi_conv_desc& d, const ConvGeom& g);
+int thinf_wgrad_launch(const srmi_conv_desc& d, const ConvGeom& g, const float* x, const float* dz, float* dw, hipStream_t s,
+                       void* ws);
+
 size_t wgrad_workspace_bytes(const srmi_conv_desc& d, const ConvGeom& g) {
     if (wgrad_fullmap(d, g)) return (size_t)d.N * d.kh * d.kw * d.Cin * sizeof(float);
+    if (thinf_wgrad_ok(d, g)) return thinf_wgrad_workspace_bytes(d, g);
     Wgrad2Plan w2;
     if (wgrad2_plan(d, g, true, &w2)) return w2.slices > 1 ? (size_t)w2.slices * w2.tiles * w2.KW * 4096 * sizeof(float) : 0;
     WgradPlan w;
@@ -431,6 +438,8 @@ int wgrad_launch(const srmi_conv_desc& d, const ConvGeom& g, const float* x, con
                            dim3(256), 0, s, (const float*)ws, dz, dw, d.N, K, d.Cout);
         return hip_check(hipGetLastError(), "wgrad_fullmap_kernel");
     }
+    if (thinf_wgrad_ok(d, g) && ws && ws_bytes >= thinf_wgrad_workspace_bytes(d, g) && !(((uintptr_t)x | (uintptr_t)dz | (uintptr_t)ws) & 15))
+        return thinf_wgrad_launch(d, g, x, dz, dw, s, ws);
     Wgrad2Plan w2;
     if (wgrad2_plan(d, g, true, &w2)) {
         if (w2.slices > 1) {

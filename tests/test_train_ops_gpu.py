@@ -56,6 +56,13 @@ CASES = [
     (2, 32, 48, 64, 64, 3, 1, False, "relu", 1, False, False, False),
     (3, 13, 21, 64, 128, 3, 1, False, "lrelu", 1, False, True, False),
     (1, 9, 70, 64, 256, 3, 1, False, "prelu", 2, False, False, False),
+    # <= 4 channels on one side (thin_f32: vector-ALU forward / dgrad / wgrad), 1..4 narrow channels, 1x1 and 3x3, BN, ragged
+    (2, 11, 13, 1, 64, 3, 1, False, "relu", 1, False, False, False),
+    (1, 9, 21, 4, 64, 3, 1, True, "lrelu", 1, False, False, False),
+    (2, 10, 7, 64, 2, 3, 1, False, "none", 1, False, True, False),
+    (3, 6, 6, 2, 64, 1, 1, False, "prelu", 1, False, False, False),
+    (2, 33, 37, 64, 4, 3, 1, False, "tanh", 1, False, False, False),
+    (4, 40, 24, 3, 64, 3, 1, False, "lrelu", 1, False, False, False),
 ]
 
 
@@ -294,3 +301,28 @@ def test_flat_adam_tracks_torch_adam():
             if pb.grad is not None:
                 assert pb._version > v0              # the packed-weight / plan caches see the update
     assert oa.param_groups[0]["lr"] == ob.param_groups[0]["lr"] == pytest.approx(1e-5)
+
+
+def test_thin_channel_convs_run_on_the_vector_kernels_and_are_deterministic():
+    """3 -> 64 and 64 -> 3 at the training step's size (16 x 96 x 96): the dispatcher names thin_f32, and forward, dgrad and
+    wgrad return the same bits on two runs (fixed pixel -> workgroup assignment, ordered partial sums)."""
+    from srmi import functional as Fn
+    for (cin, cout) in [(3, 64), (64, 3)]:
+        d = Fn.make_desc(16, 96, 96, cin, cout, 3, compute=L.COMPUTE_F32)
+        assert L.kernel_name(d) == "thin_f32"
+        g = torch.Generator().manual_seed(5)
+        x = torch.randn(16, cin, 96, 96, generator=g).to(DEV)
+        c2d = nn.Conv2d(cin, cout, 3, padding=1).to(DEV)
+        outs = []
+        for _ in range(2):
+            xd = x.clone().requires_grad_(True)
+            c2d.zero_grad(set_to_none=True)
+            y = AG.fused_conv(xd, c2d, None, None)
+            y.backward(torch.ones_like(y) * 0.5 + y.detach() * 0.1)
+            outs.append((y.detach().clone(), xd.grad.clone(), c2d.weight.grad.clone(), c2d.bias.grad.clone()))
+        for a, b in zip(*outs):
+            assert torch.equal(a, b)
+        ref = torch.nn.functional.conv2d(x.double().cpu(), c2d.weight.detach().double().cpu(), c2d.bias.detach().double().cpu(), padding=1)
+        _close(outs[0][0], ref, 1e-5, "y")
+    d9 = Fn.make_desc(16, 24, 24, 3, 64, 9, compute=L.COMPUTE_F32)          # 81 taps: stays on the MFMA kernels
+    assert L.kernel_name(d9) != "thin_f32"
