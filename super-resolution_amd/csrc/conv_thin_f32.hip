@@ -20,23 +20,42 @@ namespace srmi {
 
 typedef float thin_f2 __attribute__((ext_vector_type(2)));      // packed pairs: v_pk_fma_f32 retires two FMAs per lane and issue slot
 
-// pixel m -> (n, oy, ox), and the (clamped) offset / validity of each tap's source pixel.  K = 1 or 3 (K x K taps, stride 1).
+void f32t_magic(int d, unsigned* mul, int* sh);          // conv_f32_tiled.hip: multiply-shift constants of n / d
+
+// geometry shared by the three kernels (all wave-uniform: scalar registers)
+struct ThinGeom {
+    int H, W, pad, sign, cs;          // source tensor H x W, tap offset sign (+1 forward / -1 transposed), its channel stride
+    unsigned w_mul, h_mul; int w_sh, h_sh;
+};
+
+// pixel m -> (n, oy, ox), then for each of the K x K taps the element offset of its source pixel - clamped to the pixel's own
+// position when it falls outside the image, so every load is unconditional - and a validity bit.  The offset of a tap is the
+// pixel's plus a wave-uniform constant; rows and columns are tested once each (K + K compares, not 4 K^2).
 template <int K>
 struct ThinTaps {
-    int off[K * K];          // element offset of the source pixel (pixel index * channel stride), clamped into the tensor
-    unsigned ok;             // bit t: tap t's source pixel lies inside the image
-    __device__ __forceinline__ void set(int m, int H, int W, int pad, int sign, int cs) {
-        const int HW = H * W;
-        const int n = m / HW, rem = m - n * HW;
-        const int oy = rem / W, ox = rem - oy * W;
+    int off[K * K];
+    unsigned ok;
+    __device__ __forceinline__ void set(int m, const ThinGeom& g) {
+        const int tq = (int)(((unsigned long long)(unsigned)m * g.w_mul) >> g.w_sh);      // m / W
+        const int ox = m - tq * g.W;
+        const int n = (int)(((unsigned long long)(unsigned)tq * g.h_mul) >> g.h_sh);      // tq / H
+        const int oy = tq - n * g.H;
+        const int base = m * g.cs;
+        unsigned rok = 0u, cok = 0u;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const int iy = oy + g.sign * (k - g.pad), ix = ox + g.sign * (k - g.pad);
+            rok |= (iy >= 0 && iy < g.H) ? 1u << k : 0u;
+            cok |= (ix >= 0 && ix < g.W) ? 1u << k : 0u;
+        }
         ok = 0u;
 #pragma unroll
         for (int t = 0; t < K * K; ++t) {
             const int ky = t / K, kx = t - ky * K;
-            const int iy = oy + sign * (ky - pad), ix = ox + sign * (kx - pad);
-            const bool v = iy >= 0 && iy < H && ix >= 0 && ix < W;
+            const bool v = ((rok >> ky) & (cok >> kx) & 1u) != 0u;
             ok |= v ? 1u << t : 0u;
-            off[t] = ((n * H + (v ? iy : oy)) * W + (v ? ix : ox)) * cs;
+            const int delta = g.sign * ((ky - g.pad) * g.W + (kx - g.pad)) * g.cs;         // wave-uniform
+            off[t] = v ? base + delta : base;
         }
     }
 };
@@ -57,13 +76,13 @@ __global__ __launch_bounds__(256) void thinf_in_kernel(GenericParams p) {
     if (p.shift) sh = *(const f32x4*)(p.shift + 4 * cg);
     const float* x = (const float*)p.x;
     float* y = (float*)p.y;
-    const int sign = p.transposed ? -1 : 1;
+    const ThinGeom geo = {p.H, p.W, p.pad, p.transposed ? -1 : 1, p.in_cs, p.wo_mul, p.ho_mul, p.wo_sh, p.ho_sh};
     // software-pipelined: the loads of pixel m + stride (unconditional: clamped addresses) are in flight under the chain of m
     const int step = gridDim.x * 16;
     int m = (blockIdx.x * 4 + wave) * 4 + pg;
     ThinTaps<K> tp;
     float v[T][C];
-    tp.set(min(m, p.M - 1), p.H, p.W, p.pad, sign, p.in_cs);
+    tp.set(min(m, p.M - 1), geo);
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -71,7 +90,7 @@ __global__ __launch_bounds__(256) void thinf_in_kernel(GenericParams p) {
     for (; m < p.M; m += step) {
         ThinTaps<K> tpn;
         float vn[T][C];
-        tpn.set(min(m + step, p.M - 1), p.H, p.W, p.pad, sign, p.in_cs);
+        tpn.set(min(m + step, p.M - 1), geo);
 #pragma unroll
         for (int t = 0; t < T; ++t)
 #pragma unroll
@@ -113,33 +132,39 @@ __global__ __launch_bounds__(256) void thinf_out_kernel(GenericParams p) {
             for (int o = 0; o < P; ++o) w[t][j][o] = p.w[((size_t)t * p.Cin_pad + 4 * cg + j) * p.Cout_pad + o];
     const float* x = (const float*)p.x;
     float* y = (float*)p.y;
-    const int sign = p.transposed ? -1 : 1;
+    const ThinGeom geo = {p.H, p.W, p.pad, p.transposed ? -1 : 1, p.in_cs, p.wo_mul, p.ho_mul, p.wo_sh, p.ho_sh};
     const int step = gridDim.x * 16;
     ThinTaps<K> tp;
     f32x4 v[T];
-    tp.set(min((int)(blockIdx.x * 4 + wave) * 4 + pg, p.M - 1), p.H, p.W, p.pad, sign, p.in_cs);
+    tp.set(min((int)(blockIdx.x * 4 + wave) * 4 + pg, p.M - 1), geo);
 #pragma unroll
     for (int t = 0; t < T; ++t) v[t] = *(const f32x4*)(x + tp.off[t] + 4 * cg);
     for (int m0 = (blockIdx.x * 4 + wave) * 4; m0 < p.M; m0 += step) {       // (wave-uniform trip count: the butterfly below)
         const int m = min(m0 + pg, p.M - 1);
         ThinTaps<K> tpn;
         f32x4 vn[T];
-        tpn.set(min(m0 + step + pg, p.M - 1), p.H, p.W, p.pad, sign, p.in_cs);       // next pixel's loads under this one's chain
+        tpn.set(min(m0 + step + pg, p.M - 1), geo);       // next pixel's loads under this one's chain
 #pragma unroll
         for (int t = 0; t < T; ++t) vn[t] = *(const f32x4*)(x + tpn.off[t] + 4 * cg);
         float acc[P];
-#pragma unroll
-        for (int o = 0; o < P; ++o) acc[o] = 0.f;
+        thin_f2 a01 = {0.f, 0.f}, a23 = {0.f, 0.f};          // produced channels in packed pairs (v_pk_fma_f32)
 #pragma unroll
         for (int t = 0; t < T; ++t) {
             const bool ok = (tp.ok >> t) & 1u;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float q = ok ? v[t][j] : 0.f;
-#pragma unroll
-                for (int o = 0; o < P; ++o) acc[o] = fmaf(q, w[t][j][o], acc[o]);
+                const thin_f2 qq = {q, q};
+                if constexpr (P >= 2) a01 = __builtin_elementwise_fma(qq, (thin_f2){w[t][j][0], w[t][j][1]}, a01);
+                else a01[0] = fmaf(q, w[t][j][0], a01[0]);
+                if constexpr (P == 4) a23 = __builtin_elementwise_fma(qq, (thin_f2){w[t][j][2], w[t][j][3]}, a23);
+                else if constexpr (P == 3) a23[0] = fmaf(q, w[t][j][2], a23[0]);
             }
         }
+        acc[0] = a01[0];
+        if constexpr (P >= 2) acc[1] = a01[1];
+        if constexpr (P >= 3) acc[2] = a23[0];
+        if constexpr (P == 4) acc[3] = a23[1];
 #pragma unroll
         for (int o = 0; o < P; ++o) {
 #pragma unroll
@@ -173,7 +198,10 @@ int thinf_kind(const GenericParams& p) {
     return 0;
 }
 
-int thinf_launch(const GenericParams& p) {
+int thinf_launch(const GenericParams& p0) {
+    GenericParams p = p0;
+    f32t_magic(p.W > 0 ? p.W : 1, &p.wo_mul, &p.wo_sh);       // (source tensor = output size: stride 1, same padding)
+    f32t_magic(p.H > 0 ? p.H : 1, &p.ho_mul, &p.ho_sh);
     hipStream_t s = p.stream;
     long long nb = ((long long)p.M + 15) / 16;
     if (nb > 2048) nb = 2048;
@@ -205,6 +233,7 @@ struct ThinWgradParams {
     float* partial;                           // [workgroups][taps][S][64]
     int N, H, W, kh, kw, pad, wide_cs, narrow_cs, M;
     int sign;                                 // narrow pixel of (wide pixel m, tap) = m + sign * (tap offset - pad)
+    unsigned w_mul, h_mul; int w_sh, h_sh;    // multiply-shift division by W and H
 };
 
 template <int S, int K>
@@ -219,11 +248,12 @@ __global__ __launch_bounds__(256) void thinf_wgrad_kernel(ThinWgradParams p) {
     for (int t = 0; t < T; ++t)
 #pragma unroll
         for (int c = 0; c < S; ++c) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const ThinGeom geo = {p.H, p.W, p.pad, p.sign, p.narrow_cs, p.w_mul, p.h_mul, p.w_sh, p.h_sh};
     const int step = gridDim.x * 16;
     int m = (blockIdx.x * 4 + wave) * 4 + pg;
     ThinTaps<K> tp;
     float v[T][S];
-    tp.set(min(m, p.M - 1), p.H, p.W, p.pad, p.sign, p.narrow_cs);
+    tp.set(min(m, p.M - 1), geo);
     f32x4 wv = *(const f32x4*)(p.wide + (size_t)min(m, p.M - 1) * p.wide_cs + 4 * cg);
 #pragma unroll
     for (int t = 0; t < T; ++t)
@@ -233,7 +263,7 @@ __global__ __launch_bounds__(256) void thinf_wgrad_kernel(ThinWgradParams p) {
         ThinTaps<K> tpn;
         float vn[T][S];
         const int mn = min(m + step, p.M - 1);           // next pixel's loads under this one's chain
-        tpn.set(mn, p.H, p.W, p.pad, p.sign, p.narrow_cs);
+        tpn.set(mn, geo);
         const f32x4 wvn = *(const f32x4*)(p.wide + (size_t)mn * p.wide_cs + 4 * cg);
 #pragma unroll
         for (int t = 0; t < T; ++t)
@@ -338,6 +368,8 @@ int thinf_wgrad_launch(const srmi_conv_desc& d, const ConvGeom& g, const float* 
     ThinWgradParams p;
     p.N = d.N; p.H = d.H; p.W = d.W; p.kh = d.kh; p.kw = d.kw; p.pad = d.pad; p.M = d.N * d.H * d.W;
     p.partial = (float*)ws;
+    f32t_magic(d.W, &p.w_mul, &p.w_sh);
+    f32t_magic(d.H, &p.h_mul, &p.h_sh);
     int S;
     if (in_thin) {       // dW[co][ci][tap] = sum dz[m][co] x[m + tap - pad][ci]
         p.wide = dz; p.wide_cs = d.Cout; p.narrow = x; p.narrow_cs = g.in_cs; p.sign = 1; S = d.Cin;
