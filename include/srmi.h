@@ -399,9 +399,11 @@ int srmi_epilogue_fwd(const srmi_epi_desc* d, const float* z, const float* mean,
 
 /* Backward of srmi_epilogue_fwd w.r.t. z and the parameters, given dy (shaped like y):
  *   dz      gradient w.r.t. the conv output (same shape as z);
- *   dsum1   [C]: d beta when d->bn, else the conv bias gradient (sum of dz over pixels);
+ *   dsum1   [C]: d beta when d->bn, else the conv bias gradient (sum of dz over pixels; may be NULL when !d->bn and
+ *           nobody wants it);
  *   dsum2   [C]: d gamma (d->bn only; may be NULL otherwise);
- *   dalpha  [1] or [C/r^2]: PReLU slope gradient (may be NULL when act != PRELU).
+ *   dalpha  [1] or [C/r^2]: PReLU slope gradient (may be NULL when act != PRELU, or when the slope is frozen).
+ * Without BN and with dsum1, dsum2, dalpha and dzero all NULL nothing is reduced: one streaming launch (dense layouts).
  * The residual's gradient is dy itself.  autograd of the same modules in the reference (P/mode.py:105, :160, :178). */
 int srmi_epilogue_bwd(const srmi_epi_desc* d, const float* z, const float* dy, const float* mean, const float* rstd,
                       const float* gamma, const float* beta, const float* alpha, float* dz, float* dsum1,

@@ -300,6 +300,33 @@ __global__ __launch_bounds__(CH_BLOCK) void epilogue_bwd_v4_kernel(EpiParams p) 
     }
 }
 
+// pass 1 when NO per-channel sum is wanted (no BN, no bias / slope gradient: the frozen VGG19 stack, the discriminator's
+// plain layers in the generator step): dz = dy * act'(z), a pure stream with the arithmetic of epilogue_bwd_v4_kernel
+__global__ __launch_bounds__(CH_BLOCK) void act_bwd_v4_kernel(EpiParams p) {
+    const size_t total4 = (size_t)p.M * p.C / 4;
+    const int c0 = 4 * (int)(threadIdx.x % (unsigned)(p.C / 4));
+    f32x4 sl = {0.f, 0.f, 0.f, 0.f};
+    if (p.act == SRMI_ACT_PRELU || p.act == SRMI_ACT_LRELU || p.act == SRMI_ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sl[j] = slope_of(p, c0 + j);
+    }
+    for (size_t i = (size_t)blockIdx.x * CH_BLOCK + threadIdx.x; i < total4; i += (size_t)gridDim.x * CH_BLOCK) {
+        const f32x4 zv = *(const f32x4*)(p.z + 4 * i);
+        f32x4 g = *(const f32x4*)(p.dy + 4 * i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float u = zv[j], g0 = g[j];
+            switch (p.act) {
+                case SRMI_ACT_PRELU: case SRMI_ACT_LRELU: case SRMI_ACT_RELU: g[j] = u > 0.f ? g0 : g0 * sl[j]; break;
+                case SRMI_ACT_TANH: { const float t = tanhf(u); g[j] = g0 * (1.f - t * t); break; }
+                case SRMI_ACT_SIGMOID: { const float sg = 1.f / (1.f + expf(-u)); g[j] = g0 * sg * (1.f - sg); break; }
+                default: break;
+            }
+        }
+        *(f32x4*)(p.dz + 4 * i) = g;
+    }
+}
+
 // pass 2 (BN only): dz = gamma * rstd * (g - S1/M - zhat * S2/M)
 __global__ __launch_bounds__(CH_BLOCK) void bn_bwd_apply_v4_kernel(EpiParams p) {
     const size_t total4 = (size_t)p.M * p.C / 4;
@@ -575,6 +602,12 @@ int epilogue_bwd(const srmi_epi_desc& d, const float* z, const float* dy, const 
     p.z = z; p.dy = dy; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.alpha = alpha;
     p.dz = dz; p.acc = (double*)ws;
     const int n_alpha = d.act == SRMI_ACT_PRELU ? (d.alpha_per_channel ? p.Cf : 1) : 0;
+    if (!d.bn && !dsum1 && !dsum2 && !dalpha && !dzero && p.r == 1 && lane_keeps_channels(p.C) &&
+        vec4_ptrs({z, dy, dz, p.alpha_pc ? alpha : nullptr})) {      // nothing to reduce: one streaming launch
+        if (p.M == 0) return SRMI_OK;
+        hipLaunchKernelGGL(act_bwd_v4_kernel, dim3(ew_blocks((size_t)p.M * p.C / 4)), dim3(CH_BLOCK), 0, s, p);
+        return hip_check(hipGetLastError(), "act_bwd_v4_kernel");
+    }
     const dim3 grid = ch_grid(p.M > 0 ? p.M : 1, p.C);
     p.nslots = p.M > 0 ? (int)grid.x : 0;
     int rc;

@@ -268,16 +268,19 @@ class FusedConvFn(torch.autograd.Function):
         Cout = desc.Cout
         dz = torch.empty_like(z)
         ws = _train_ws(Cout, dev)
-        dsum1 = torch.empty(Cout, dtype=torch.float32, device=dev)
+        need = ctx.needs_input_grad
+        # per-channel sums only where somebody wants them: BN's backward, the bias gradient, the PReLU slope gradient
+        # (none of them in the frozen VGG19 stack: its epilogue backward is then one streaming launch)
+        want_bias = ctx.has_bias and need[2]
+        dsum1 = torch.empty(Cout, dtype=torch.float32, device=dev) if (cfg.bn is not None or want_bias) else None
         dsum2 = torch.empty(Cout, dtype=torch.float32, device=dev) if cfg.bn is not None else None
-        dalpha = torch.empty_like(alpha) if alpha is not None else None
+        dalpha = torch.empty_like(alpha) if (alpha is not None and need[5]) else None
         # the bias of a conv feeding train-mode BN has an exactly-zero gradient (BN removes the mean): zero-filled by the
         # finalize launch of the epilogue backward, not by a fill launch of its own
         dzero = torch.empty(Cout, dtype=torch.float32, device=dev) if (cfg.bn is not None and ctx.has_bias) else None
         L.check(lib.srmi_epilogue_bwd(C.byref(ed), z.data_ptr(), dy.data_ptr(), _ptr(mean), _ptr(rstd), _ptr(gamma),
-                                      _ptr(beta), _ptr(alpha), dz.data_ptr(), dsum1.data_ptr(), _ptr(dsum2),
+                                      _ptr(beta), _ptr(alpha), dz.data_ptr(), _ptr(dsum1), _ptr(dsum2),
                                       _ptr(dalpha), _ptr(dzero), ws.data_ptr(), st))
-        need = ctx.needs_input_grad
         dx = dw = dbias = dgamma = dbeta = None
         if need[1]:
             dw = torch.empty_like(w)
@@ -298,8 +301,8 @@ class FusedConvFn(torch.autograd.Function):
             dgamma, dbeta = dsum2, dsum1
             dbias = dzero
         else:
-            dbias = dsum1 if ctx.has_bias else None
-        return dx, dw, dbias, dgamma, dbeta, dalpha if need[5] else None, dy if ctx.has_res else None, None
+            dbias = dsum1 if want_bias else None
+        return dx, dw, dbias, dgamma, dbeta, dalpha, dy if ctx.has_res else None, None
 
 
 def fused_conv(x, c2d: nn.Conv2d, bn, act, residual=None, shuffle=1, shuffle_order=L.SHUFFLE_CRD, weight=None, pad=None):

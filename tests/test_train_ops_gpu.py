@@ -136,6 +136,34 @@ def test_fused_conv_forward_backward(case):
         _close(resd.grad, leaves["res"].grad, what="dres")
 
 
+@pytest.mark.parametrize("act", ["relu", "lrelu", "prelu", "tanh", "none"])
+def test_frozen_layer_backward_streams_and_matches(act):
+    """A layer without BN whose parameters are frozen (the VGG19 stack, P/vgg19.py; the discriminator in the generator
+    step) wants no per-channel sum: its epilogue backward is one streaming launch (srmi_epilogue_bwd with every sum
+    pointer NULL).  dx must be the dx of the summing path, bit for bit."""
+    g = torch.Generator().manual_seed(77)
+    x = torch.randn(3, 64, 19, 23, generator=g)
+    gy = torch.randn(3, 128, 19, 23, generator=g)
+    c2d = nn.Conv2d(64, 128, 3, padding=1).to(DEV)
+    actm = {"none": None, "prelu": nn.PReLU(), "lrelu": nn.LeakyReLU(), "relu": nn.ReLU(), "tanh": nn.Tanh()}[act]
+    if act == "prelu":
+        actm = actm.to(DEV)
+    outs = []
+    for frozen in (False, True):
+        for p_ in list(c2d.parameters()) + (list(actm.parameters()) if act == "prelu" else []):
+            p_.requires_grad_(not frozen)
+            p_.grad = None
+        xd = x.to(DEV).requires_grad_(True)
+        y = AG.fused_conv(xd, c2d, None, actm)
+        y.backward(gy.to(DEV))
+        outs.append(xd.grad.clone())
+        if frozen:
+            assert c2d.bias.grad is None and c2d.weight.grad is None
+        else:
+            assert c2d.bias.grad is not None
+    assert torch.equal(outs[0], outs[1])
+
+
 # (3,8,3,3,10): gathering dgrad + MFMA wgrad; the others take the full-map forms (dgrad as a forward GEMM with the
 # [co][tap][ci] operand, the outer-product wgrad through the transposed x) and, at 256 outputs, the tiled forward pack
 @pytest.mark.parametrize("shape", [(3, 8, 3, 3, 10), (5, 128, 6, 6, 40), (4, 128, 6, 6, 256), (16, 32, 12, 12, 64),

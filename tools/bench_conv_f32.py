@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--only", default="")
     ap.add_argument("--filter", default="")
+    ap.add_argument("--batch", type=int, default=0, help="override the batch size of every shape (default: 16, config 3)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     lib = L.load()
@@ -69,6 +70,7 @@ def main():
     print(f"{'layer':26s} {'GFLOP':>7s} | {'fwd us':>8s} {'TF/s':>6s} | {'dgrad us':>8s} {'TF/s':>6s} | {'wgrad us':>8s} {'TF/s':>6s}")
     tot = [0.0, 0.0, 0.0, 0.0]
     for label, N, H, W, Cin, Cout, k, s, *rest in SHAPES:
+        N = args.batch or N
         if args.filter and args.filter not in label:
             continue
         pad = rest[0] if rest else k // 2
