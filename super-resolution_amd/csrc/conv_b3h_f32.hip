@@ -1,5 +1,5 @@
 // Split-bf16 f32 conv (see conv_b3_f32.hip for the arithmetic) for THE shape of the SRGAN generator's body: 3x3, stride 1,
-// pad 1, 64 contracted channels, 64 g produced channels, NHWC f32, linear epilogue (scale, shift, f32 residual) -
+// pad 1, 64 contracted channels, 64 g produced channels, NHWC f32, epilogue scale, shift, slope activation, f32 residual -
 // forward, or the stride-1 dgrad of such a layer (transposed = 1).
 //
 // The general kernel re-loads and re-splits a pixel tile for each of the 9 taps and hands every 32/64-channel chunk over
@@ -43,6 +43,7 @@ struct B3hParams {
     int in_cs, out_cs, out_co, res_cs;
     int tiles_x, tiles_y;
     int transposed;
+    const float* alpha; int act, alpha_pc; float act_param;      // slope activations (none / ReLU / LeakyReLU / PReLU)
 };
 
 __global__ __launch_bounds__(256) void conv_b3h_kernel(B3hParams p) {
@@ -136,6 +137,9 @@ __global__ __launch_bounds__(256) void conv_b3h_kernel(B3hParams p) {
     const int co = 32 * nt + i;
     const float sc = p.scale ? p.scale[co] : 1.f;
     const float sh = p.shift ? p.shift[co] : 0.f;
+    // slope of the negative side, as generic_epilogue_flat applies it (1: no activation)
+    const float sl = p.act == SRMI_ACT_PRELU ? p.alpha[p.alpha_pc ? co : 0] : p.act == SRMI_ACT_LRELU ? p.act_param
+                   : p.act == SRMI_ACT_RELU ? 0.f : 1.f;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int q = 32 * wm + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -143,6 +147,7 @@ __global__ __launch_bounds__(256) void conv_b3h_kernel(B3hParams p) {
         if (oy < p.H && ox < p.W) {
             const size_t pix = (size_t)(n * p.H + oy) * p.W + ox;
             float v = (acc0[e] + acc1[e]) * sc + sh;
+            v = v >= 0.f ? v : v * sl;
             if (p.res) v += p.res[pix * p.res_cs + co];
             p.y[pix * p.out_cs + p.out_co + co] = v;
         }
@@ -187,7 +192,8 @@ static bool b3h_enabled() {
 bool b3h_fwd_ok(const srmi_conv_desc& d) {
     return b3h_enabled() && d.compute == SRMI_COMPUTE_F32 && d.in_layout == SRMI_NHWC && d.in_dtype == SRMI_F32 &&
            d.out_layout == SRMI_NHWC && d.out_dtype == SRMI_F32 && d.res_dtype == SRMI_F32 && d.kh == 3 && d.kw == 3 &&
-           d.stride == 1 && d.pad == 1 && d.Cin == 64 && d.Cout % 64 == 0 && d.Cout / 64 <= 65535 && d.act == SRMI_ACT_NONE &&
+           d.stride == 1 && d.pad == 1 && d.Cin == 64 && d.Cout % 64 == 0 && d.Cout / 64 <= 65535 &&
+           (d.act == SRMI_ACT_NONE || d.act == SRMI_ACT_RELU || d.act == SRMI_ACT_LRELU || d.act == SRMI_ACT_PRELU) &&
            d.shuffle == 1;
 }
 bool b3h_dgrad_ok(const srmi_conv_desc& d) {
@@ -210,9 +216,10 @@ int b3h_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, int t
 // loudly: no other kernel can read this operand.
 int b3h_launch(const GenericParams& g) {
     if (g.in_bf16 || g.in_nchw || g.out_bf16 || g.out_nchw || g.res_bf16 || g.in_cs % 4 != 0 || ((uintptr_t)g.x & 15) ||
-        g.act != SRMI_ACT_NONE || g.r != 1 || g.Cin != 64 || g.Cout % 64 != 0 || g.kh != 3 || g.kw != 3 || g.stride != 1 ||
+        !(g.act == SRMI_ACT_NONE || g.act == SRMI_ACT_RELU || g.act == SRMI_ACT_LRELU || g.act == SRMI_ACT_PRELU) ||
+        (g.act == SRMI_ACT_PRELU && !g.alpha) || g.r != 1 || g.Cin != 64 || g.Cout % 64 != 0 || g.kh != 3 || g.kw != 3 || g.stride != 1 ||
         g.pad != 1 || g.H != g.Ho || g.W != g.Wo) {
-        set_error("conv (split-bf16 3x3 / 64-channel kernel): NHWC f32 in / out with 16-byte aligned rows, no activation");
+        set_error("conv (split-bf16 3x3 / 64-channel kernel): NHWC f32 in / out with 16-byte aligned rows, slope activations only");
         return SRMI_EUNSUPPORTED;
     }
     B3hParams p;
@@ -222,6 +229,7 @@ int b3h_launch(const GenericParams& g) {
     p.in_cs = g.in_cs; p.out_cs = g.out_cs; p.out_co = g.out_co; p.res_cs = g.res_cs;
     p.tiles_x = (p.W + B3H_T - 1) / B3H_T; p.tiles_y = (p.H + B3H_T - 1) / B3H_T;
     p.transposed = g.transposed;
+    p.alpha = g.alpha; p.act = g.act; p.alpha_pc = g.alpha_pc; p.act_param = g.act_param;
     const long long tiles = (long long)p.tiles_x * p.tiles_y * p.N;
     if (tiles <= 0) return SRMI_OK;
     if (tiles > 0x7fffffffLL) { set_error("conv (split-bf16 3x3 kernel): too many tiles"); return SRMI_EINVAL; }

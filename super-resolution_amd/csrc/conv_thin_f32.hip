@@ -73,7 +73,14 @@ __global__ __launch_bounds__(256) void thinf_in_kernel(GenericParams p) {
 #pragma unroll
         for (int c = 0; c < C; ++c) w[t][c] = *(const f32x4*)(p.w + ((size_t)t * p.Cin_pad + c) * p.Cout_pad + 4 * cg);
     f32x4 sh = {0.f, 0.f, 0.f, 0.f};
-    if (p.shift) sh = *(const f32x4*)(p.shift + 4 * cg);
+    if (p.shift) sh = (f32x4){p.shift[4 * cg], p.shift[4 * cg + 1], p.shift[4 * cg + 2], p.shift[4 * cg + 3]};   // (4-byte aligned only)
+    // slope of the negative side, as generic_epilogue_flat applies it (1: no activation)
+    const float sl0 = p.act == SRMI_ACT_LRELU ? p.act_param : p.act == SRMI_ACT_RELU ? 0.f : 1.f;
+    f32x4 sl = {sl0, sl0, sl0, sl0};
+    if (p.act == SRMI_ACT_PRELU) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) sl[j] = p.alpha[p.alpha_pc ? 4 * cg + j : 0];
+    }
     const float* x = (const float*)p.x;
     float* y = (float*)p.y;
     const ThinGeom geo = {p.H, p.W, p.pad, p.transposed ? -1 : 1, p.in_cs, p.wo_mul, p.ho_mul, p.wo_sh, p.ho_sh};
@@ -105,7 +112,9 @@ __global__ __launch_bounds__(256) void thinf_in_kernel(GenericParams p) {
                 a01 = __builtin_elementwise_fma(qq, (thin_f2){w[t][c][0], w[t][c][1]}, a01);
                 a23 = __builtin_elementwise_fma(qq, (thin_f2){w[t][c][2], w[t][c][3]}, a23);
             }
-        const f32x4 acc = (f32x4){a01[0], a01[1], a23[0], a23[1]} + sh;
+        f32x4 acc = (f32x4){a01[0], a01[1], a23[0], a23[1]} + sh;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[j] = acc[j] >= 0.f ? acc[j] : acc[j] * sl[j];
         *(f32x4*)(y + (size_t)m * p.out_cs + p.out_co + 4 * cg) = acc;
         tp = tpn;
 #pragma unroll
@@ -183,7 +192,7 @@ __global__ __launch_bounds__(256) void thinf_out_kernel(GenericParams p) {
 }
 
 static bool thinf_linear(const GenericParams& p) {
-    return !p.scale && p.act == SRMI_ACT_NONE && !p.res && p.r == 1 && !p.in_nchw && !p.out_nchw && !p.in_bf16 && !p.out_bf16 &&
+    return !p.scale && !p.res && p.r == 1 && !p.in_nchw && !p.out_nchw && !p.in_bf16 && !p.out_bf16 &&
            p.stride == 1 && p.kh == p.kw && (p.kh == 1 || p.kh == 3) && 2 * p.pad == p.kh - 1 && p.Ho == p.H && p.Wo == p.W && !p.b3 &&
            (long long)p.N * p.H * p.W * (p.in_cs > p.out_cs ? p.in_cs : p.out_cs) < 0x7fffffffLL;       // 32-bit element offsets
 }
@@ -192,9 +201,12 @@ static bool thinf_linear(const GenericParams& p) {
 int thinf_kind(const GenericParams& p) {
     if (dbg_flags() & (1 << 11)) return 0;
     if (!thinf_linear(p)) return 0;
-    if (((uintptr_t)p.x | (uintptr_t)p.y | (uintptr_t)p.w | (uintptr_t)p.shift) & 15) return 0;
-    if (p.Cin >= 1 && p.Cin <= 4 && p.Cout == 64 && p.Cout_pad == 64 && p.out_cs % 4 == 0 && p.out_co % 4 == 0) return 1;
-    if (p.Cout >= 1 && p.Cout <= 4 && p.Cin == 64 && p.in_cs % 4 == 0) return 2;
+    if (((uintptr_t)p.x | (uintptr_t)p.y | (uintptr_t)p.w) & 15) return 0;
+    const bool slope = p.act == SRMI_ACT_RELU || p.act == SRMI_ACT_LRELU || p.act == SRMI_ACT_PRELU;   // (PReLU: the API checks alpha)
+    if (p.Cin >= 1 && p.Cin <= 4 && p.Cout == 64 && p.Cout_pad == 64 && p.out_cs % 4 == 0 && p.out_co % 4 == 0 &&
+        (p.act == SRMI_ACT_NONE || slope))
+        return 1;
+    if (p.Cout >= 1 && p.Cout <= 4 && p.Cin == 64 && p.in_cs % 4 == 0 && p.act == SRMI_ACT_NONE) return 2;
     return 0;
 }
 

@@ -42,6 +42,9 @@ __device__ __forceinline__ size_t final_index(const EpiParams& p, int m, int c, 
     return (((size_t)n * p.H * p.r + (size_t)oy * p.r + si) * ((size_t)p.W * p.r) + (size_t)ox * p.r + sj) * p.Cf + cf;
 }
 
+// four consecutive per-channel constants (4-byte aligned only: parameters may be views into a flat optimizer buffer)
+__device__ __forceinline__ f32x4 ld4(const float* q) { return f32x4{q[0], q[1], q[2], q[3]}; }
+
 __device__ __forceinline__ float slope_of(const EpiParams& p, int cf) {
     if (p.act == SRMI_ACT_PRELU) return p.alpha[p.alpha_pc ? cf : 0];
     if (p.act == SRMI_ACT_LRELU) return p.act_param;
@@ -179,9 +182,9 @@ __global__ __launch_bounds__(CH_BLOCK) void epilogue_fwd_v4_kernel(EpiParams p) 
     const size_t total4 = (size_t)p.M * p.C / 4;
     const int c0 = 4 * (int)(threadIdx.x % (unsigned)(p.C / 4));
     f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = mu, ga = mu, be = mu, al = mu;
-    if (p.bn) { mu = *(const f32x4*)(p.mean + c0); rs = *(const f32x4*)(p.rstd + c0); ga = *(const f32x4*)(p.gamma + c0); be = *(const f32x4*)(p.beta + c0); }
+    if (p.bn) { mu = ld4(p.mean + c0); rs = ld4(p.rstd + c0); ga = ld4(p.gamma + c0); be = ld4(p.beta + c0); }
     if (p.act == SRMI_ACT_PRELU) {
-        if (p.alpha_pc) al = *(const f32x4*)(p.alpha + c0);
+        if (p.alpha_pc) al = ld4(p.alpha + c0);
         else { const float a0 = p.alpha[0]; al = f32x4{a0, a0, a0, a0}; }
     }
     for (size_t i = (size_t)blockIdx.x * CH_BLOCK + threadIdx.x; i < total4; i += (size_t)gridDim.x * CH_BLOCK) {
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(CH_BLOCK) void epilogue_bwd_v4_kernel(EpiParams p) 
     double s1[4] = {0.0, 0.0, 0.0, 0.0}, s2[4] = {0.0, 0.0, 0.0, 0.0}, s3[4] = {0.0, 0.0, 0.0, 0.0};
     if (c0 < p.C) {
         f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = {1.f, 1.f, 1.f, 1.f}, ga = rs, be = mu, sl = mu;
-        if (p.bn) { mu = *(const f32x4*)(p.mean + c0); rs = *(const f32x4*)(p.rstd + c0); ga = *(const f32x4*)(p.gamma + c0); be = *(const f32x4*)(p.beta + c0); }
+        if (p.bn) { mu = ld4(p.mean + c0); rs = ld4(p.rstd + c0); ga = ld4(p.gamma + c0); be = ld4(p.beta + c0); }
         if (p.act == SRMI_ACT_PRELU || p.act == SRMI_ACT_LRELU || p.act == SRMI_ACT_RELU) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) sl[j] = slope_of(p, c0 + j);
@@ -333,7 +336,7 @@ __global__ __launch_bounds__(CH_BLOCK) void bn_bwd_apply_v4_kernel(EpiParams p) 
     const double invM = 1.0 / (double)p.M;
     const int c0 = 4 * (int)(threadIdx.x % (unsigned)(p.C / 4));
     const double* tot = p.acc + (size_t)p.nslots * 3 * p.C;           // totals, written by the finalize launch
-    const f32x4 mu = *(const f32x4*)(p.mean + c0), rs = *(const f32x4*)(p.rstd + c0), ga = *(const f32x4*)(p.gamma + c0);
+    const f32x4 mu = ld4(p.mean + c0), rs = ld4(p.rstd + c0), ga = ld4(p.gamma + c0);
     f32x4 m1, m2;
 #pragma unroll
     for (int j = 0; j < 4; ++j) { m1[j] = (float)(tot[c0 + j] * invM); m2[j] = (float)(tot[p.C + c0 + j] * invM); }
@@ -588,7 +591,7 @@ int epilogue_fwd(const srmi_epi_desc& d, const float* z, const float* mean, cons
     p.z = z; p.mean = mean; p.rstd = rstd; p.gamma = gamma; p.beta = beta; p.alpha = alpha; p.residual = residual;
     p.y = y;
     if (p.M == 0) return SRMI_OK;
-    if (p.r == 1 && lane_keeps_channels(p.C) && vec4_ptrs({z, y, residual, mean, rstd, gamma, beta, p.alpha_pc ? alpha : nullptr}))
+    if (p.r == 1 && lane_keeps_channels(p.C) && vec4_ptrs({z, y, residual}))
         hipLaunchKernelGGL(epilogue_fwd_v4_kernel, dim3(ew_blocks((size_t)p.M * p.C / 4)), dim3(CH_BLOCK), 0, s, p);
     else
         hipLaunchKernelGGL(epilogue_fwd_kernel, dim3(ew_blocks((size_t)p.M * p.C)), dim3(CH_BLOCK), 0, s, p);
@@ -603,7 +606,7 @@ int epilogue_bwd(const srmi_epi_desc& d, const float* z, const float* dy, const 
     p.dz = dz; p.acc = (double*)ws;
     const int n_alpha = d.act == SRMI_ACT_PRELU ? (d.alpha_per_channel ? p.Cf : 1) : 0;
     if (!d.bn && !dsum1 && !dsum2 && !dalpha && !dzero && p.r == 1 && lane_keeps_channels(p.C) &&
-        vec4_ptrs({z, dy, dz, p.alpha_pc ? alpha : nullptr})) {      // nothing to reduce: one streaming launch
+        vec4_ptrs({z, dy, dz})) {      // nothing to reduce: one streaming launch
         if (p.M == 0) return SRMI_OK;
         hipLaunchKernelGGL(act_bwd_v4_kernel, dim3(ew_blocks((size_t)p.M * p.C / 4)), dim3(CH_BLOCK), 0, s, p);
         return hip_check(hipGetLastError(), "act_bwd_v4_kernel");
@@ -612,7 +615,7 @@ int epilogue_bwd(const srmi_epi_desc& d, const float* z, const float* dy, const 
     p.nslots = p.M > 0 ? (int)grid.x : 0;
     int rc;
     if (p.M > 0) {
-        if (p.r == 1 && p.C % 4 == 0 && vec4_ptrs({z, dy, dz, mean, rstd, gamma, beta}))
+        if (p.r == 1 && p.C % 4 == 0 && vec4_ptrs({z, dy, dz}))
             hipLaunchKernelGGL(epilogue_bwd_v4_kernel, grid, dim3(CH_BLOCK), 0, s, p);
         else
             hipLaunchKernelGGL(epilogue_bwd_kernel, grid, dim3(CH_BLOCK), 0, s, p);
@@ -625,7 +628,7 @@ int epilogue_bwd(const srmi_epi_desc& d, const float* z, const float* dy, const 
     rc = hip_check(hipGetLastError(), "epilogue_bwd_finalize_kernel");
     if (rc) return rc;
     if (p.M > 0 && d.bn) {
-        if (lane_keeps_channels(p.C) && vec4_ptrs({z, dz, mean, rstd, gamma}))
+        if (lane_keeps_channels(p.C) && vec4_ptrs({z, dz}))
             hipLaunchKernelGGL(bn_bwd_apply_v4_kernel, dim3(ew_blocks((size_t)p.M * p.C / 4)), dim3(CH_BLOCK), 0, s, p);
         else
             hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(ew_blocks((size_t)p.M * p.C)), dim3(CH_BLOCK), 0, s, p);

@@ -126,9 +126,10 @@ class _ConvPlan:
     __slots__ = ("desc", "Ho", "Wo", "ws_fwd", "ws_dgrad", "ws_wgrad", "dgrad_pack_bytes")
 
     def __init__(self, key):
-        N, H, W, Cin, Cout, kh, kw, stride, pad = key
+        N, H, W, Cin, Cout, kh, kw, stride, pad, act, act_param = key
         lib = L.load()
         self.desc = Fn.make_desc(N, H, W, Cin, Cout, (kh, kw), stride=stride, pad=pad, compute=L.COMPUTE_F32)
+        self.desc.act, self.desc.act_param = act, act_param      # (only the forward launch reads them)
         _, _, self.Ho, self.Wo = Fn.out_shape(self.desc)
         n = C.c_size_t(0)
         L.check(lib.srmi_conv2d_workspace_bytes(C.byref(self.desc), C.byref(n)))
@@ -145,8 +146,8 @@ _PLANS = {}
 _PLANS_LOCK = threading.Lock()
 
 
-def _conv_plan(N, H, W, Cin, Cout, kh, kw, stride, pad):
-    key = (N, H, W, Cin, Cout, kh, kw, stride, pad)
+def _conv_plan(N, H, W, Cin, Cout, kh, kw, stride, pad, act=L.ACT_NONE, act_param=0.0):
+    key = (N, H, W, Cin, Cout, kh, kw, stride, pad, act, act_param)
     pl = _PLANS.get(key)
     if pl is None:
         with _PLANS_LOCK:
@@ -216,6 +217,24 @@ class FusedConvFn(torch.autograd.Function):
         # N: sub-pixel / full-map / halo-tile forms - so those are part of the cache key)
         wp = _PACKS.get(("fwd", H, W, cfg.stride, cfg.pad), weight, lambda: Fn.pack_weights(desc, w))
         shift = bias.detach().contiguous() if bias is not None else None
+        bn = cfg.bn
+        # ReLU / LeakyReLU of a layer without BN, residual or sub-pixel store (the VGG19 stack, D's first conv and Linear)
+        # go into the conv launch when that launch does not split K (a split needs a linear epilogue): no second pass
+        # over the output, and y alone is kept - its sign is the pre-activation's, all the backward needs.
+        if (bn is None and residual is None and cfg.shuffle == 1 and plan.ws_fwd == 0 and N * Ho * Wo > 0 and
+                (cfg.act == L.ACT_RELU or (cfg.act == L.ACT_LRELU and cfg.act_param > 0.0))):
+            planf = _conv_plan(N, H, W, Cin, Cout, kh, kw, cfg.stride, cfg.pad, cfg.act, float(cfg.act_param))
+            if planf.ws_fwd == 0:
+                y = _empty_cl((N, Cout, Ho, Wo), dev)
+                a = L.ConvArgs()
+                Fn.fill_args(a, planf.desc, x, wp, None, shift, None, None, y)
+                L.check(lib.srmi_conv2d_fwd_ws(C.byref(a), None, 0, st))
+                ed = L.EpiDesc(N, Ho, Wo, Cout, cfg.act, cfg.act_param, cfg.apc, 1, cfg.order, 0)
+                ctx.save_for_backward(x, w, y, None, None, None, None, None)
+                ctx.cfg, ctx.desc, ctx.ed, ctx.plan = cfg, desc, ed, plan
+                ctx.has_bias, ctx.has_res = bias is not None, False
+                ctx.weight_obj = weight
+                return y
         z = _empty_cl((N, Cout, Ho, Wo), dev)
         # scale NULL = 1: lets the kernel split K on small maps; the workspace makes that split deterministic
         a = L.ConvArgs()
@@ -223,7 +242,6 @@ class FusedConvFn(torch.autograd.Function):
         wsk = _WS.get(plan.ws_fwd, dev)
         L.check(lib.srmi_conv2d_fwd_ws(C.byref(a), _ptr(wsk), plan.ws_fwd, st))
 
-        bn = cfg.bn
         mean = rstd = None
         M = N * Ho * Wo
         if bn is not None:

@@ -53,13 +53,17 @@ def test_kernel_selection():
     d = Fn.make_desc(16, 96, 96, 64, 64, 3)                      # f32 compute -> f32 path
     # Cin, Cout multiples of 32: three bf16 planes of the split-operand kernel; [tap][Cin][Cout] f32 with SRMI_F32_EXACT=1
     exact = os.environ.get("SRMI_F32_EXACT", "0") not in ("", "0")
-    # the name is the kernel that RUNS: 3x3 / 64 channels / no activation -> the halo-tile split kernel, with an
-    # activation the general split kernel (a different operand order in the same byte count: srmi.h)
+    # the name is the kernel that RUNS: 3x3 / 64 channels / slope activation or none -> the halo-tile split kernel, any
+    # other activation -> the general split kernel (a different operand order in the same byte count: srmi.h)
     assert L.kernel_name(d) == ("f32t" if exact else "b3h_f32")
     d_relu = Fn.make_desc(16, 96, 96, 64, 64, 3, act=L.ACT_RELU)
-    assert L.kernel_name(d_relu) == ("f32t" if exact else "b3_f32")
+    assert L.kernel_name(d_relu) == ("f32t" if exact else "b3h_f32")
+    d_tanh = Fn.make_desc(16, 96, 96, 64, 64, 3, act=L.ACT_TANH)
+    assert L.kernel_name(d_tanh) == ("f32t" if exact else "b3_f32")
     assert L.kernel_name(Fn.make_desc(1, 8, 8, 3, 64, 9, in_layout=L.NCHW)) == "generic_f32"    # NCHW input: no LDS-tiled kernel
-    assert L.kernel_name(Fn.make_desc(2, 8, 8, 64, 3, 3)) == "f32t"                             # Cout % 32 != 0: exact f32 MFMA
+    assert L.kernel_name(Fn.make_desc(2, 8, 8, 64, 24, 3)) == "f32t"                            # Cout % 32 != 0: exact f32 MFMA
+    assert L.kernel_name(Fn.make_desc(2, 8, 8, 64, 3, 3)) == "thin_f32"                         # <= 4 channels on one side: vector ALU
+    assert L.kernel_name(Fn.make_desc(2, 8, 8, 3, 64, 3, act=L.ACT_LRELU, act_param=0.2)) == "thin_f32"
     assert L.packed_weight_bytes(d) == (9 * 64 * 64 * 4 if exact else 3 * 9 * 64 * 64 * 2)
     d = Fn.make_desc(1, 8, 8, 3, 64, 9)                          # Cin padded to 8, Cout to 64
     assert L.packed_weight_bytes(d) == 81 * 8 * 64 * 4

@@ -164,6 +164,71 @@ def test_frozen_layer_backward_streams_and_matches(act):
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("shape", [(2, 64, 128, 33, 29, 3, 1), (2, 128, 128, 24, 24, 3, 1), (3, 3, 64, 40, 24, 3, 1),
+                                   (3, 64, 64, 32, 32, 3, 2), (4, 512, 512, 6, 6, 3, 1)])
+@pytest.mark.parametrize("act", ["relu", "lrelu"])
+def test_relu_in_the_conv_launch_equals_the_separate_epilogue(shape, act):
+    """ReLU / LeakyReLU of a layer without BN run inside the conv launch when it does not split K (srmi/autograd.py): y
+    and dx must equal conv (no activation) followed by the activation, bit for bit (the last shape splits K and keeps
+    the separate epilogue; halo-tile, general split, thin and stride-2 kernels before it)."""
+    N, Cin, Cout, H, W, k, stride = shape
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    c2d = nn.Conv2d(Cin, Cout, k, stride=stride, padding=1).to(DEV)
+    slope = 0.0 if act == "relu" else 0.2
+    actm = nn.ReLU() if act == "relu" else nn.LeakyReLU(0.2)
+    xd = x.to(DEV).requires_grad_(True)
+    y = AG.fused_conv(xd, c2d, None, actm)
+    gy = torch.randn(y.shape, generator=g).to(DEV)
+    y.backward(gy)
+    dx, dw, db = xd.grad.clone(), c2d.weight.grad.clone(), c2d.bias.grad.clone()
+    c2d.weight.grad = c2d.bias.grad = None
+    xe = x.to(DEV).requires_grad_(True)
+    z = AG.fused_conv(xe, c2d, None, None)
+    ye = torch.where(z >= 0, z, z * slope)
+    assert torch.equal(y, ye)
+    # the activation's backward as the library defines it (slope on z <= 0), through the linear layer's backward
+    z.backward(torch.where(z > 0, gy, gy * slope))
+    assert torch.equal(dx, xe.grad) and torch.equal(dw, c2d.weight.grad) and torch.equal(db, c2d.bias.grad)
+
+
+def test_parameters_inside_a_flat_buffer_keep_the_fast_kernels_and_the_bits():
+    """srmi.optim.Adam re-points every parameter at a view of one flat buffer: behind a 1-element PReLU slope the
+    per-channel vectors (bias, gamma, beta) are only 4-byte aligned.  Same results, bit for bit, as with aligned ones."""
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(2, 64, 12, 12, generator=g)
+    x3 = torch.randn(2, 64, 12, 12, generator=g)
+    gy = torch.randn(2, 64, 12, 12, generator=g).to(DEV)
+    gy3 = torch.randn(2, 3, 12, 12, generator=g).to(DEV)
+    c2d, bnm, act = nn.Conv2d(64, 64, 3, padding=1).to(DEV), nn.BatchNorm2d(64).to(DEV).train(), nn.PReLU().to(DEV)
+    last = nn.Conv2d(64, 3, 3, padding=1).to(DEV)          # thin_f32 forward: the bias is read 4 bytes at a time
+    with torch.no_grad():
+        bnm.weight.uniform_(0.5, 1.5, generator=None); bnm.bias.normal_(0, 0.2)
+    outs = []
+    for misalign in (False, True):
+        if misalign:
+            for p_ in [c2d.bias, bnm.weight, bnm.bias, last.bias]:
+                buf = torch.zeros(p_.numel() + 5, device=DEV)
+                view = buf[1:1 + p_.numel()]
+                view.copy_(p_.data)
+                p_.data = view
+                assert p_.data_ptr() % 16 == 4
+        for p_ in list(c2d.parameters()) + list(bnm.parameters()) + list(act.parameters()) + list(last.parameters()):
+            p_.grad = None
+        bnm.running_mean.zero_(); bnm.running_var.fill_(1.0)
+        xd = x.to(DEV).requires_grad_(True)
+        y = AG.fused_conv(xd, c2d, bnm, act)
+        y.backward(gy)
+        xl = x3.to(DEV).requires_grad_(True)
+        y3 = AG.fused_conv(xl, last, None, nn.Tanh())
+        y3.backward(gy3)
+        assert L.kernel_name(AG._conv_plan(2, 12, 12, 64, 3, 3, 3, 1, 1).desc) == "thin_f32"
+        outs.append([t.clone() for t in (y, xd.grad, c2d.weight.grad, bnm.weight.grad, bnm.bias.grad, act.weight.grad,
+                                         bnm.running_var, y3, xl.grad, last.weight.grad, last.bias.grad)])
+    for a_, b_ in zip(*outs):
+        assert torch.equal(a_, b_)
+
+
 # (3,8,3,3,10): gathering dgrad + MFMA wgrad; the others take the full-map forms (dgrad as a forward GEMM with the
 # [co][tap][ci] operand, the outer-product wgrad through the transposed x) and, at 256 outputs, the tiled forward pack
 @pytest.mark.parametrize("shape", [(3, 8, 3, 3, 10), (5, 128, 6, 6, 40), (4, 128, 6, 6, 256), (16, 32, 12, 12, 64),
