@@ -169,7 +169,7 @@ const char* srmi_last_error(void);
 /* name of the kernel that RUNS the forward conv of `d`: bf16 path "c64_bf16", "cin_bf16", "c64_thin_bf16", "k9c3_bf16",
  * "k9c1_bf16", "pw_bf16", "c1out_bf16"; f32 path "b3h_f32" (split-bf16, 3x3 / 64 input channels, halo tile in LDS),
  * "b3_f32" (split-bf16, general), "f32t" (exact f32 MFMA, LDS-tiled), "thin_f32" (<= 4 channels on one side, stride 1,
- * <= 9 taps, linear epilogue: fmaf chains on the vector ALU, HBM-bound), "generic_f32" (exact f32 MFMA, no LDS: NCHW or
+ * <= 9 taps, shift-only epilogue plus - on the <= 4 -> 64 side - a slope activation: fmaf chains on the vector ALU, HBM-bound), "generic_f32" (exact f32 MFMA, no LDS: NCHW or
  * bf16-storage inputs, odd shapes).  The packed-weight FORMAT is a property of this name (see below). */
 int srmi_conv2d_kernel_name(const srmi_conv_desc* d, char* buf, size_t buf_len);
 
@@ -191,10 +191,10 @@ int srmi_srcnn_layer_c1out(const srmi_conv_args* a, void* stream);
  * the weight's shape:
  *   "b3_f32"   SRMI_COMPUTE_F32, NHWC f32 input, Cin and Cout multiples of 32, <= 25 taps, kh*kw*Cin >= 256:
  *              [plane][tap][n][k] bf16, three planes (6 B per weight);
- *   "b3h_f32"  the same AND 3x3, stride 1, pad 1, Cin == 64, Cout % 64 == 0, act == SRMI_ACT_NONE, shuffle == 1,
- *              NHWC f32 output and f32 residual: [plane][tap][nt][ks][lane][8] bf16 - the SAME byte count as "b3_f32"
- *              in a different order, so e.g. an act = NONE and an act = RELU descriptor of one 64 -> 64 3x3 weight need
- *              two packed buffers (a mismatch is not detectable from the size);
+ *   "b3h_f32"  the same AND 3x3, stride 1, pad 1, Cin == 64, Cout % 64 == 0, act one of NONE / RELU / LRELU / PRELU (the
+ *              slope activations), shuffle == 1, NHWC f32 output and f32 residual: [plane][tap][nt][ks][lane][8] bf16 -
+ *              the SAME byte count as "b3_f32" in a different order, so e.g. an act = RELU and an act = TANH descriptor
+ *              of one 64 -> 64 3x3 weight need two packed buffers (a mismatch is not detectable from the size);
  *   "f32t" / "thin_f32" / "generic_f32"  [tap][Cin_pad][Cout_pad] f32 (one format: these three may share a buffer).
  * Environment SRMI_F32_EXACT=1 (read once, at the first call) keeps every f32 conv on the exact-f32 MFMA kernels and
  * their format. */
