@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SRMI_VERSION 117 /* 0.1.7: SRMI_CONV_FUSE_CHAIN + srmi_chain_status + SRMI_ETIMEOUT; 0.1.6: srmi_conv_args.x_copy; 0.1.5: srmi_adam_step takes double hyper-parameters (0.1.4: bn_train_stats counts num_batches_tracked, epilogue_bwd zero-fills the BN-fed bias gradient;
+#define SRMI_VERSION 118 /* 0.1.8: SRMI_FUSE_K9PW, srmi_epilogue_bwd takes NULL sum pointers; 0.1.7: SRMI_CONV_FUSE_CHAIN + srmi_chain_status + SRMI_ETIMEOUT; 0.1.6: srmi_conv_args.x_copy; 0.1.5: srmi_adam_step takes double hyper-parameters (0.1.4: bn_train_stats counts num_batches_tracked, epilogue_bwd zero-fills the BN-fed bias gradient;
                             srmi_conv2d_kernel_name reports the f32 kernel that runs) */
 
 /* error codes */
@@ -239,9 +239,14 @@ int srmi_chain_status(void);
 int srmi_conv2d_chain_length(const srmi_conv_args* a, int32_t n);
 
 /* Non-zero if srmi_conv2d_fwd_seq would run (conv1 flagged SRMI_CONV_FUSE_NEXT, conv2) as one fused launch:
- * SRMI_FUSE_RESBLOCK (the pair above) or SRMI_FUSE_UPTAIL (below); 0 if they go out as two launches. */
+ * SRMI_FUSE_RESBLOCK (the pair above), SRMI_FUSE_UPTAIL (below) or SRMI_FUSE_K9PW; 0 if they go out as two launches. */
 #define SRMI_FUSE_RESBLOCK 1
 #define SRMI_FUSE_UPTAIL 2
+#define SRMI_FUSE_K9PW 3     /* "k9c1pw_bf16": 9x9 conv of a one-channel f32 image to 64 channels + activation, then a 1x1 conv
+                                64 -> 32 + activation (SRCNN 9-1-5, SRCNN/srcnn.py:205-208 with the 64/32 widths): the 64-channel
+                                tensor never reaches memory (4 B in, 64 B out per pixel instead of 4 + 128 + 128 + 64); conv1 packed
+                                for "k9c1_bf16", conv2 for "pw_bf16", dense bf16 NHWC in between, no residuals.  Bit-identical to
+                                the two launches. */
 int srmi_conv2d_can_fuse(const srmi_conv_args* conv1, const srmi_conv_args* conv2);
 
 /* Any fusable pair in one launch (the kind srmi_conv2d_can_fuse reports); SRMI_EUNSUPPORTED otherwise.

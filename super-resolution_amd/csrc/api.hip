@@ -284,21 +284,23 @@ int srmi_conv2d_fwd_ws(const srmi_conv_args* a, void* ws, size_t ws_bytes, void*
     return conv_fwd_one(a, (hipStream_t)stream, ws, ws_bytes);
 }
 
-// 0: not fusable; 1: the ResBlock pair (conv_resblock_bf16.hip); 2: up conv + PixelShuffle + last conv (conv_upfuse_bf16.hip)
+// 0: not fusable; 1: the ResBlock pair (conv_resblock_bf16.hip); 2: up conv + PixelShuffle + last conv (conv_upfuse_bf16.hip);
+// 3: 9x9 conv of a one-channel image + 1x1 conv (conv_k9c1_bf16.hip)
 static int fuse_kind(const srmi_conv_args* a1, const srmi_conv_args* a2) {
     ConvGeom g;
     if (conv_geom(a1->d, &g) || conv_geom(a2->d, &g)) return 0;
     if (a1->x_copy || a2->x_copy) return 0;          // the fused kernels do not write input copies: two launches
     const bool rb = resblock_supported(a1->d, a2->d);
     const bool uf = !rb && upfuse_supported(a1->d, a2->d);
-    if (!rb && !uf) return 0;
+    const bool kp = !rb && !uf && k9pw_supported(a1->d, a2->d);
+    if (!rb && !uf && !kp) return 0;
     if (a1->residual || !a1->x || !a1->w || !a2->w || !a2->y || !a1->scale || !a1->shift || !a2->scale || !a2->shift)
         return 0;
     if ((a1->d.act == SRMI_ACT_PRELU && !a1->alpha) || (a2->d.act == SRMI_ACT_PRELU && !a2->alpha)) return 0;
     if (a2->x && a2->x != a1->y) return 0;
     if (a2->y == a1->x) return 0;
-    if (uf && a2->residual) return 0;
-    return rb ? 1 : 2;
+    if ((uf || kp) && a2->residual) return 0;
+    return rb ? 1 : uf ? 2 : 3;
 }
 
 static bool can_fuse_pair(const srmi_conv_args* a1, const srmi_conv_args* a2) { return fuse_kind(a1, a2) == 1; }
@@ -317,6 +319,7 @@ int srmi_conv2d_fwd_pair(const srmi_conv_args* conv1, const srmi_conv_args* conv
     switch (fuse_kind(conv1, conv2)) {
     case 1: return resblock_launch(*conv1, *conv2, (hipStream_t)stream);
     case 2: return upfuse_launch(*conv1, *conv2, (hipStream_t)stream);
+    case 3: return k9pw_launch(*conv1, *conv2, (hipStream_t)stream);
     }
     set_error("fwd_pair: not a fusable pair (see srmi_conv2d_can_fuse)");
     return SRMI_EUNSUPPORTED;
@@ -363,11 +366,14 @@ int srmi_conv2d_fwd_seq(const srmi_conv_args* a, int32_t n, void* stream) {
             ++i;
             continue;
         }
-        if ((a[i].flags & SRMI_CONV_FUSE_NEXT) && i + 1 < n && fuse_kind(a + i, a + i + 1) == 2) {
-            int rc = upfuse_launch(a[i], a[i + 1], (hipStream_t)stream);
-            if (rc) return rc;
-            ++i;
-            continue;
+        if ((a[i].flags & SRMI_CONV_FUSE_NEXT) && i + 1 < n) {
+            const int kind = fuse_kind(a + i, a + i + 1);
+            if (kind == 2 || kind == 3) {
+                int rc = kind == 2 ? upfuse_launch(a[i], a[i + 1], (hipStream_t)stream) : k9pw_launch(a[i], a[i + 1], (hipStream_t)stream);
+                if (rc) return rc;
+                ++i;
+                continue;
+            }
         }
         int rc = conv_fwd_one(a + i, (hipStream_t)stream);
         if (rc) return rc;

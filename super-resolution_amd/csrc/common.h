@@ -146,6 +146,8 @@ int chain_launch(const srmi_conv_args* a, int head, int npairs, const int* kinds
 int chain_status();
 // fused generator tail: up conv 64->256 + PixelShuffle(2) + PReLU + last conv 64->3 + tanh (conv_upfuse_bf16.hip)
 bool upfuse_supported(const srmi_conv_desc& d1, const srmi_conv_desc& d2);
+bool k9pw_supported(const srmi_conv_desc& d1, const srmi_conv_desc& d2);      // conv_k9c1_bf16.hip: 9x9 1 -> 64 + 1x1 64 -> 32
+int k9pw_launch(const srmi_conv_args& a1, const srmi_conv_args& a2, hipStream_t s);
 int upfuse_launch(const srmi_conv_args& a1, const srmi_conv_args& a2, hipStream_t s);
 
 }  // namespace srmi

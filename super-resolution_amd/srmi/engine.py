@@ -155,7 +155,7 @@ class _Seq:
             if (arr[i].flags & L.CONV_FUSE_NEXT) and i + 1 < n:
                 kind = lib.srmi_conv2d_can_fuse(C.byref(arr[i]), C.byref(arr[i + 1]))
             if kind:
-                out.append(({1: "resblock_bf16", 2: "upfuse_bf16"}[kind], i, 2))
+                out.append(({1: "resblock_bf16", 2: "upfuse_bf16", 3: "k9c1pw_bf16"}[kind], i, 2))
                 i += 2
             else:
                 out.append((kernels[i], i, 1))

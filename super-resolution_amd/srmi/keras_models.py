@@ -68,7 +68,8 @@ class SRCNNPlan(_Plan):
         s = _Seq(dev, compute)
         relu = nn.ReLU()
         b1 = s.buf(N, H, W, m.conv1.out_channels)
-        s.add((m.conv1, None, relu), None, b1, N, H, W, in_layout=L.NCHW, in_dtype=L.F32)
+        # (9-1-5 with 64 / 32 channels in bf16: conv1 + conv2 go out as ONE launch, "k9c1pw_bf16"; b1 is then never written)
+        s.add((m.conv1, None, relu), None, b1, N, H, W, in_layout=L.NCHW, in_dtype=L.F32, fuse_next=True)
         b2 = s.buf(N, H, W, m.conv2.out_channels)
         s.add((m.conv2, None, relu), b1, b2, N, H, W)
         self.out_shape = (N, m.conv3.out_channels, H, W)

@@ -537,3 +537,60 @@ def test_pool_and_upsample_addressing_ops(dtype):
     assert torch.all(out[..., :off] == 7.0) and torch.all(out[..., off + Cc:] == 7.0)
     assert lib.srmi_upsample2x_nhwc(x.data_ptr(), out.data_ptr(), N, 3, 5, Cc, CS, CS - 4, code, None) == -1     # slice overruns
     assert lib.srmi_maxpool2x2_nhwc(None, None, 0, 4, 4, 8, 0, code, None) == 0                                   # empty batch
+
+
+@pytest.mark.parametrize("case", [
+    dict(N=2, H=9, W=7, act1=L.ACT_RELU, act2=L.ACT_RELU),                     # smaller than the window reach
+    dict(N=1, H=16, W=64, act1=L.ACT_RELU, act2=L.ACT_RELU),                   # exactly one tile
+    dict(N=2, H=37, W=150, act1=L.ACT_RELU, act2=L.ACT_RELU),                  # ragged in both directions
+    dict(N=1, H=21, W=67, act1=L.ACT_PRELU, act2=L.ACT_PRELU, apc2=1),         # scalar slope, then per-channel slopes
+    dict(N=1, H=8, W=130, act1=L.ACT_LRELU, act2=L.ACT_NONE, out_cs=56, out_co=16),   # the 32 channels into a channel slice
+])
+def test_k9c1_pw_fused_pair(case):
+    """SRCNN 9-1-5 (BASELINE config 2): conv 9x9 1 -> 64 + activation and conv 1x1 64 -> 32 + activation as ONE launch
+    ("k9c1pw_bf16", SRMI_FUSE_K9PW): the 64-channel tensor stays in registers.  Bit-identical to the two launches."""
+    import ctypes as C
+    g = _rng(41)
+    N, H, W = case["N"], case["H"], case["W"]
+    act1, act2, apc2 = case["act1"], case["act2"], case.get("apc2", 0)
+    out_cs, out_co = case.get("out_cs", 0), case.get("out_co", 0)
+    x = torch.from_numpy(g.uniform(-1, 1, (N, 1, H, W)).astype(np.float32)).to(DEV)
+    w1 = torch.from_numpy((g.standard_normal((64, 1, 9, 9)) / 9.0).astype(np.float32)).to(DEV)
+    w2 = torch.from_numpy((g.standard_normal((32, 64, 1, 1)) / 8.0).astype(np.float32)).to(DEV)
+    par = lambda n: (torch.from_numpy(g.uniform(0.5, 1.5, n).astype(np.float32)).to(DEV),
+                     torch.from_numpy(g.uniform(-0.3, 0.3, n).astype(np.float32)).to(DEV))
+    (sc1, sh1), (sc2, sh2) = par(64), par(32)
+    al1 = torch.tensor([0.2], device=DEV)
+    al2 = torch.from_numpy(g.uniform(0.05, 0.4, 32 if apc2 else 1).astype(np.float32)).to(DEV)
+    d1 = Fn.make_desc(N, H, W, 1, 64, 9, in_dtype=L.F32, out_dtype=L.BF16, in_layout=L.NCHW, compute=L.COMPUTE_BF16,
+                      act=act1, act_param=0.1)
+    d2 = Fn.make_desc(N, H, W, 64, 32, 1, in_dtype=L.BF16, out_dtype=L.BF16, compute=L.COMPUTE_BF16, act=act2, act_param=0.3,
+                      alpha_per_channel=apc2, out_cstride=out_cs, out_coffset=out_co)
+    assert L.kernel_name(d1) == "k9c1_bf16" and L.kernel_name(d2) == "pw_bf16"
+    wp1, wp2 = Fn.pack_weights(d1, w1), Fn.pack_weights(d2, w2)
+    mid = torch.zeros((N, H, W, 64), dtype=torch.bfloat16, device=DEV)
+    outs = []
+    for fused in (False, True):
+        y = torch.full((N, H, W, out_cs or 32), 3.0, dtype=torch.bfloat16, device=DEV)
+        arr = (L.ConvArgs * 2)()
+        Fn.fill_args(arr[0], d1, x, wp1, sc1, sh1, al1 if act1 == L.ACT_PRELU else None, None, mid)
+        Fn.fill_args(arr[1], d2, mid, wp2, sc2, sh2, al2 if act2 == L.ACT_PRELU else None, None, y)
+        arr[0].flags = L.CONV_FUSE_NEXT if fused else 0
+        lib = L.load()
+        assert lib.srmi_conv2d_can_fuse(C.byref(arr[0]), C.byref(arr[1])) == 3
+        if fused:
+            mid.fill_(-7.0)                 # the fused launch must neither read nor need it
+        L.check(lib.srmi_conv2d_fwd_seq(arr, 2, Fn.stream_ptr()))
+        torch.cuda.synchronize()
+        if fused:
+            assert float(mid.float().abs().min()) == 7.0 and float(mid.float().max()) == -7.0
+        outs.append(y.clone())
+    assert torch.equal(outs[0].view(torch.int16), outs[1].view(torch.int16))
+    if out_cs:                               # channels outside the slice untouched
+        assert float(outs[1][..., :out_co].float().min()) == 3.0 and float(outs[1][..., out_co + 32:].float().max()) == 3.0
+    # and the pair against the f64 restatement (bf16 inputs / weights / intermediate, one output rounding)
+    t = _ref_fused(x.cpu().bfloat16().float(), w1.cpu().bfloat16().float(), sc1.cpu(), sh1.cpu(), act1, 0.1, al1.cpu(), None, 1, 4, 1, False)
+    ref = _ref_fused(t.float().bfloat16().float(), w2.cpu().bfloat16().float(), sc2.cpu(), sh2.cpu(), act2, 0.3, al2.cpu(), None, 1, 0, 1, False)
+    got = outs[1][..., out_co:out_co + 32].float().cpu().permute(0, 3, 1, 2)
+    err = (got.double() - ref).abs()
+    assert torch.all(err <= 2.0 ** -7 * (ref.abs() + 1.0)), err.max().item()

@@ -28,9 +28,12 @@ def run(name, model, x, out_px, flop_per_step, steps, warmup, compute, per_layer
         torch.cuda.synchronize()
         el = (time.perf_counter() - t0) / steps
     plan = model._plans.get(model, x.shape[0], x.shape[2], x.shape[3], 1 if compute == "bf16" else 0)
+    from srmi.engine import _Seq
+    plan.args[0].x = x.data_ptr()
+    units = _Seq.launches(plan.args, plan.n, plan.kernels)          # what srmi_conv2d_fwd_seq launches (fused pairs as one)
     rec = {"workload": name, "compute": compute, "ms_per_step": round(el * 1e3, 3),
            "out_mp_per_s": round(out_px / 1e6 / el, 1), "tflops": round(flop_per_step / el / 1e12, 1),
-           "kernels": dict(collections.Counter(plan.kernels))}
+           "kernels": dict(collections.Counter(u[0] for u in units))}
     if per_layer:
         rec["layers"] = layer_table(plan, x)
         # the whole net against its compulsory traffic (input + output only: what ONE fused launch would move)
@@ -49,28 +52,38 @@ def layer_table(plan, x, reps=10):
     import ctypes as C
     from srmi import _lib as L
     from srmi import functional as Fn
+    from srmi.engine import _Seq
     lib, st = L.load(), Fn.stream_ptr()
     plan.args[0].x = x.data_ptr()
     esz = {L.F32: 4, L.BF16: 2}
-    tot = [0.0] * plan.n
+    units = _Seq.launches(plan.args, plan.n, plan.kernels)          # (label, first conv, count): fused pairs are ONE launch
+    tot = [0.0] * len(units)
     for _ in range(reps):
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(plan.n + 1)]
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(len(units) + 1)]
         ev[0].record()
-        for i in range(plan.n):
-            L.check(lib.srmi_conv2d_fwd(C.byref(plan.args[i]), st))
-            ev[i + 1].record()
+        for u, (label, i, cnt) in enumerate(units):
+            if cnt == 1:
+                L.check(lib.srmi_conv2d_fwd(C.byref(plan.args[i]), st))
+            elif cnt == 2:
+                L.check(lib.srmi_conv2d_fwd_pair(C.byref(plan.args[i]), C.byref(plan.args[i + 1]), st))
+            else:
+                L.check(lib.srmi_conv2d_fwd_seq(C.byref(plan.args[i]), cnt, st))
+            ev[u + 1].record()
         torch.cuda.synchronize()
-        for i in range(plan.n):
-            tot[i] += ev[i].elapsed_time(ev[i + 1]) * 1e-3 / reps
+        for u in range(len(units)):
+            tot[u] += ev[u].elapsed_time(ev[u + 1]) * 1e-3 / reps
     out = {}
-    for i in range(plan.n):
-        d = plan.args[i].d
-        px = d.N * d.H * d.W
-        nbytes = px * (d.Cin * esz[d.in_dtype] + d.Cout * esz[d.out_dtype])
-        flops = 2.0 * px * d.Cin * d.Cout * d.kh * d.kw
-        out[f"{i}:{plan.kernels[i]}:{d.Cin}->{d.Cout}k{d.kh}"] = {
-            "us": round(tot[i] * 1e6, 1), "algorithmic_bytes": nbytes, "GB/s": round(nbytes / tot[i] / 1e9, 1),
-            "frac_of_8TB/s": round(nbytes / tot[i] / HBM_PEAK, 4), "tflops": round(flops / tot[i] / 1e12, 1)}
+    for u, (label, i, cnt) in enumerate(units):
+        d0, d1 = plan.args[i].d, plan.args[i + cnt - 1].d
+        px = d0.N * d0.H * d0.W
+        # algorithmic bytes of the LAUNCH: its first conv's input + its last conv's output, each once
+        nbytes = px * d0.Cin * esz[d0.in_dtype] + d1.N * d1.H * d1.W * d1.Cout * esz[d1.out_dtype]
+        flops = sum(2.0 * plan.args[j].d.N * plan.args[j].d.H * plan.args[j].d.W * plan.args[j].d.Cin * plan.args[j].d.Cout *
+                    plan.args[j].d.kh * plan.args[j].d.kw for j in range(i, i + cnt))
+        chans = "->".join([str(d0.Cin)] + [str(plan.args[j].d.Cout) for j in range(i, i + cnt)])
+        out[f"{i}:{label}:{chans}k{d0.kh}"] = {
+            "us": round(tot[u] * 1e6, 1), "algorithmic_bytes": nbytes, "GB/s": round(nbytes / tot[u] / 1e9, 1),
+            "frac_of_8TB/s": round(nbytes / tot[u] / HBM_PEAK, 4), "tflops": round(flops / tot[u] / 1e12, 1)}
     return out
 
 
