@@ -40,7 +40,7 @@ struct K9c1Params {
     int out_cs2, out_co2, act2, alpha_pc2; float act_param2;
 };
 
-constexpr int K9C1_TH = 8, K9C1_TW = 64, K9C1_LH = K9C1_TH + 8, K9C1_LW = K9C1_TW + 10;      // (even; column +9 is read, weight 0)
+constexpr int K9C1_TH = 8, K9C1_TW = 64, K9C1_LW = K9C1_TW + 10;      // (even; column +9 is read, weight 0)
 
 // A fragments [group][mt][ks][lane][8]: lane = 16 kq + r, row r of M tile mt = channel 64 g + 32 (mt >> 1) + 8 (r >> 2) + 4 (mt & 1) + (r & 3),
 // K index 32 ks + 8 kq + i = 10 dy + dx, zero for dx = 9 and from 90 on
@@ -56,9 +56,9 @@ __global__ void k9c1_pack_kernel(const float* __restrict__ w, bf16_t* __restrict
     out[i] = (kk < 90 && dx < 9) ? f2bf(w[(size_t)ch * 81 + dy * 9 + dx]) : (bf16_t)0;
 }
 
-template <int MT2>      // 0: the 9x9 conv alone; 2: + 1x1 conv 64 -> 32
-__global__ __launch_bounds__(256) void k9c1_kernel(K9c1Params p) {
-    constexpr int TH = K9C1_TH, TW = K9C1_TW, LH = K9C1_LH, LW = K9C1_LW;
+template <int MT2, int TH>      // MT2 = 0: the 9x9 conv alone; 2: + 1x1 conv 64 -> 32.  TH: rows per workgroup
+__global__ __launch_bounds__(256, 3) void k9c1_kernel(K9c1Params p) {      // (3 workgroups per CU: 168 registers hold the fused form without spills; 2 -> 3 waves per SIMD: 138 -> 112 us; 4: 37 spills, 470 us)
+    constexpr int TW = K9C1_TW, LH = TH + 8, LW = K9C1_LW;
     __shared__ __attribute__((aligned(16))) bf16_t tile[2 * LH * LW];      // [1]: the same tile shifted left by one pixel
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int pl = lane & 15, q = lane >> 4;
@@ -234,7 +234,7 @@ int k9c1_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     p.tiles_x = (d.W + K9C1_TW - 1) / K9C1_TW; p.tiles_y = (d.H + K9C1_TH - 1) / K9C1_TH;
     const long long nb = (long long)d.N * p.tiles_x * p.tiles_y;
     if (nb > 0x7fffffffLL) { set_error("k9c1_bf16: grid too large"); return SRMI_EINVAL; }
-    hipLaunchKernelGGL(k9c1_kernel<0>, dim3((unsigned)nb, (unsigned)(d.Cout / 64)), dim3(256), 0, s, p);
+    hipLaunchKernelGGL((k9c1_kernel<0, K9C1_TH>), dim3((unsigned)nb, (unsigned)(d.Cout / 64)), dim3(256), 0, s, p);
     return hip_check(hipGetLastError(), "k9c1_kernel");
 }
 
@@ -270,10 +270,16 @@ int k9pw_launch(const srmi_conv_args& a1, const srmi_conv_args& a2, hipStream_t 
     p.out_cs2 = d2.out_cstride ? d2.out_cstride : d2.Cout; p.out_co2 = d2.out_coffset;
     p.act2 = d2.act; p.alpha_pc2 = d2.alpha_per_channel; p.act_param2 = d2.act_param;
     if (d.N == 0 || d.H == 0 || d.W == 0) return SRMI_OK;
-    p.tiles_x = (d.W + K9C1_TW - 1) / K9C1_TW; p.tiles_y = (d.H + K9C1_TH - 1) / K9C1_TH;
+    // The fused pair is bound by MFMA issue, not by its output stream: taller tiles amortise the workgroup's prologue
+    // (input tile staged twice, 64 registers of weights) and the 8 halo rows
+    const int th = exp_flags() & 3 ? 4 << (exp_flags() & 3) : 32;       // 32 rows: 161 (8 rows) -> 138 us at 32x384x384; SRMI_EXP 1..3 (ablation build): 8 / 16 / 32... rows
+    p.tiles_x = (d.W + K9C1_TW - 1) / K9C1_TW; p.tiles_y = (d.H + th - 1) / th;
     const long long nb = (long long)d.N * p.tiles_x * p.tiles_y;
     if (nb > 0x7fffffffLL) { set_error("k9c1pw_bf16: grid too large"); return SRMI_EINVAL; }
-    hipLaunchKernelGGL(k9c1_kernel<2>, dim3((unsigned)nb, 1u), dim3(256), 0, s, p);
+    if (th == 8) hipLaunchKernelGGL((k9c1_kernel<2, 8>), dim3((unsigned)nb, 1u), dim3(256), 0, s, p);
+    else if (th == 16) hipLaunchKernelGGL((k9c1_kernel<2, 16>), dim3((unsigned)nb, 1u), dim3(256), 0, s, p);
+    else if (th == 32) hipLaunchKernelGGL((k9c1_kernel<2, 32>), dim3((unsigned)nb, 1u), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((k9c1_kernel<2, 32>), dim3((unsigned)nb, 1u), dim3(256), 0, s, p);
     return hip_check(hipGetLastError(), "k9c1pw_kernel");
 }
 
