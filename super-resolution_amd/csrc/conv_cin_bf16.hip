@@ -17,6 +17,8 @@
 // generic f32 kernel's.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "c64_common.h"
 
 namespace srmi {
@@ -173,44 +175,58 @@ __global__ __launch_bounds__(NW * 64, WGPC) void conv_cin_kernel(CinParams p) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
 
-        bf16x8 afr[2][NCT], bfr[2][PT];
-        {
-            const unsigned char* wslot = wring + ((kc * 9) & (CIN_WRING - 1)) * TAP_BYTES + lane * 16;
+        // K steps of this chunk: 9 taps x 2 halves of 32 channels - or, when the chunk holds only 32 real channels (the last
+        // chunk of Cin = 96 / 160 / 32: its upper half is zero-filled, its packed weights there are zero), the 9 lower
+        // halves alone: the skipped MFMAs would add exact zeros (same bits), 25 % of a 96-channel layer's matrix work.
+        auto ksteps = [&](auto HALFC) {
+            constexpr bool HALF = decltype(HALFC)::value;
+            constexpr int NS = HALF ? 9 : 18;
+            bf16x8 afr[2][NCT], bfr[2][PT];
+            {
+                const unsigned char* wslot = wring + ((kc * 9) & (CIN_WRING - 1)) * TAP_BYTES + lane * 16;
 #pragma unroll
-            for (int t = 0; t < NCT; ++t) afr[0][t] = *(const bf16x8*)(wslot + t * 1024);
+                for (int t = 0; t < NCT; ++t) afr[0][t] = *(const bf16x8*)(wslot + t * 1024);
 #pragma unroll
-            for (int k = 0; k < PT; ++k) bfr[0][k] = *(const bf16x8*)(lds + boff[k][0]);
-        }
-#pragma unroll
-        for (int j = 0; j < 18; ++j) {
-            const int tap = j >> 1, half = j & 1;
-            const int g = kc * 9 + tap;
-            if (half == 1) {
-                // tap g+1 landed (own copy: counted vmcnt, tap g+2 may stay in flight; others': barrier);
-                // the barrier also retires every wave's reads of tap g-1, whose slot tap g+3 re-uses
-                if (g + 2 < ntap) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                if (g + 3 < ntap) issue_tap(g + 3);
+                for (int k = 0; k < PT; ++k) bfr[0][k] = *(const bf16x8*)(lds + boff[k][0]);
             }
-            if (j + 1 < 18) {
-                const int tapn = (j + 1) >> 1, halfn = (j + 1) & 1;
-                const int dyn = tapn / 3, dxn = tapn - 3 * dyn;
-                const unsigned char* wslot =
-                    wring + ((kc * 9 + tapn) & (CIN_WRING - 1)) * TAP_BYTES + lane * 16 + halfn * (NCT * 1024);
 #pragma unroll
-                for (int t = 0; t < NCT; ++t) afr[(j + 1) & 1][t] = *(const bf16x8*)(wslot + t * 1024);
+            for (int j = 0; j < NS; ++j) {
+                const int tap = HALF ? j : j >> 1, half = HALF ? 0 : j & 1;
+                const int g = kc * 9 + tap;
+                if (HALF || half == 1) {
+                    // tap g+1 landed (own copy: counted vmcnt, tap g+2 may stay in flight; others': barrier);
+                    // the barrier also retires every wave's reads of tap g-1, whose slot tap g+3 re-uses
+                    if (g + 2 < ntap) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+                    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    __builtin_amdgcn_s_barrier();
+                    if (g + 3 < ntap) issue_tap(g + 3);
+                }
+                if (j + 1 < NS) {
+                    const int tapn = HALF ? j + 1 : (j + 1) >> 1, halfn = HALF ? 0 : (j + 1) & 1;
+                    const int dyn = tapn / 3, dxn = tapn - 3 * dyn;
+                    const unsigned char* wslot =
+                        wring + ((kc * 9 + tapn) & (CIN_WRING - 1)) * TAP_BYTES + lane * 16 + halfn * (NCT * 1024);
+#pragma unroll
+                    for (int t = 0; t < NCT; ++t) afr[(j + 1) & 1][t] = *(const bf16x8*)(wslot + t * 1024);
+#pragma unroll
+                    for (int k = 0; k < PT; ++k)
+                        bfr[(j + 1) & 1][k] =
+                            *(const bf16x8*)(lds + ((boff[k][dxn] ^ (halfn << 6)) + dyn * (ROWP * 128)));
+                }
 #pragma unroll
                 for (int k = 0; k < PT; ++k)
-                    bfr[(j + 1) & 1][k] =
-                        *(const bf16x8*)(lds + ((boff[k][dxn] ^ (halfn << 6)) + dyn * (ROWP * 128)));
+#pragma unroll
+                    for (int t = 0; t < NCT; ++t)
+                        acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[j & 1][t], bfr[j & 1][k], acc[k][t], 0, 0, 0);
+                if (j + 1 < NS) sched_interleave<0, NCT + PT, NCT * PT>();
             }
-#pragma unroll
-            for (int k = 0; k < PT; ++k)
-#pragma unroll
-                for (int t = 0; t < NCT; ++t)
-                    acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[j & 1][t], bfr[j & 1][k], acc[k][t], 0, 0, 0);
-            if (j + 1 < 18) sched_interleave<0, NCT + PT, NCT * PT>();
+        };
+        // (the 8-wave, 64-channel variants run at the 256-register budget: a second unrolled loop costs them 23-75 spills)
+        constexpr bool HALF_OK = !(NCT == 4 && NW == 8);
+        if (HALF_OK && p.Cin - kc * 64 <= 32) {
+            if constexpr (HALF_OK) ksteps(std::true_type{});
+        } else {
+            ksteps(std::false_type{});
         }
     }
 
