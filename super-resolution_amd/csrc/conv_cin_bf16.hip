@@ -34,7 +34,9 @@ struct CinParams {
 
 constexpr int CIN_WRING = 4;
 
-template <int TH, int TWT, int NCT, int NW, int WGPC = 1>
+// SKIPH (8-wave, 64-channel variants, launched for Cin % 64 == 32): in a chunk that holds only 32 real channels the
+// MFMAs of the upper half-steps are branched around (their operand reads stay: one loop body, no second unrolled copy)
+template <int TH, int TWT, int NCT, int NW, int WGPC = 1, bool SKIPH = false>
 __global__ __launch_bounds__(NW * 64, WGPC) void conv_cin_kernel(CinParams p) {
     constexpr int NTH = NW * 64;
     constexpr int TW = TWT * 16;
@@ -178,6 +180,7 @@ __global__ __launch_bounds__(NW * 64, WGPC) void conv_cin_kernel(CinParams p) {
         // K steps of this chunk: 9 taps x 2 halves of 32 channels - or, when the chunk holds only 32 real channels (the last
         // chunk of Cin = 96 / 160 / 32: its upper half is zero-filled, its packed weights there are zero), the 9 lower
         // halves alone: the skipped MFMAs would add exact zeros (same bits), 25 % of a 96-channel layer's matrix work.
+        const bool halfchunk = p.Cin - kc * 64 <= 32;
         auto ksteps = [&](auto HALFC) {
             constexpr bool HALF = decltype(HALFC)::value;
             constexpr int NS = HALF ? 9 : 18;
@@ -213,17 +216,19 @@ __global__ __launch_bounds__(NW * 64, WGPC) void conv_cin_kernel(CinParams p) {
                         bfr[(j + 1) & 1][k] =
                             *(const bf16x8*)(lds + ((boff[k][dxn] ^ (halfn << 6)) + dyn * (ROWP * 128)));
                 }
+                if (!(SKIPH && half == 1 && halfchunk)) {
 #pragma unroll
-                for (int k = 0; k < PT; ++k)
+                    for (int k = 0; k < PT; ++k)
 #pragma unroll
-                    for (int t = 0; t < NCT; ++t)
-                        acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[j & 1][t], bfr[j & 1][k], acc[k][t], 0, 0, 0);
+                        for (int t = 0; t < NCT; ++t)
+                            acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[j & 1][t], bfr[j & 1][k], acc[k][t], 0, 0, 0);
+                }
                 if (j + 1 < NS) sched_interleave<0, NCT + PT, NCT * PT>();
             }
         };
         // (the 8-wave, 64-channel variants run at the 256-register budget: a second unrolled loop costs them 23-75 spills)
         constexpr bool HALF_OK = !(NCT == 4 && NW == 8);
-        if (HALF_OK && p.Cin - kc * 64 <= 32) {
+        if (HALF_OK && halfchunk) {
             if constexpr (HALF_OK) ksteps(std::true_type{});
         } else {
             ksteps(std::false_type{});
@@ -363,8 +368,10 @@ int cin_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     const dim3 grid((unsigned)nb, gy);
     // the two big tiles run with 8 waves (two per SIMD hide each other's LDS / barrier / staging bubbles)
     if (tile == 3) hipLaunchKernelGGL((conv_cin_kernel<8, 2, 2, 4, 2>), grid, dim3(256), 0, s, p);
+    else if (tile == 0 && nct == 4 && d.Cin % 64 == 32) hipLaunchKernelGGL((conv_cin_kernel<6, 6, 4, 8, 1, true>), grid, dim3(512), 0, s, p);
     else if (tile == 0 && nct == 4) hipLaunchKernelGGL((conv_cin_kernel<6, 6, 4, 8>), grid, dim3(512), 0, s, p);
     else if (tile == 0) hipLaunchKernelGGL((conv_cin_kernel<6, 6, 2, 8>), grid, dim3(512), 0, s, p);
+    else if (tile == 1 && nct == 4 && d.Cin % 64 == 32) hipLaunchKernelGGL((conv_cin_kernel<8, 4, 4, 8, 1, true>), grid, dim3(512), 0, s, p);
     else if (tile == 1 && nct == 4) hipLaunchKernelGGL((conv_cin_kernel<8, 4, 4, 8>), grid, dim3(512), 0, s, p);
     else if (tile == 1) hipLaunchKernelGGL((conv_cin_kernel<8, 4, 2, 8>), grid, dim3(512), 0, s, p);
     else if (nct == 4) hipLaunchKernelGGL((conv_cin_kernel<4, 2, 4, 4>), grid, dim3(256), 0, s, p);
