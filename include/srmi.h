@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SRMI_VERSION 118 /* 0.1.8: SRMI_FUSE_K9PW, srmi_epilogue_bwd takes NULL sum pointers; 0.1.7: SRMI_CONV_FUSE_CHAIN + srmi_chain_status + SRMI_ETIMEOUT; 0.1.6: srmi_conv_args.x_copy; 0.1.5: srmi_adam_step takes double hyper-parameters (0.1.4: bn_train_stats counts num_batches_tracked, epilogue_bwd zero-fills the BN-fed bias gradient;
+#define SRMI_VERSION 119 /* 0.1.9: srmi_bn_train_stats_n; 0.1.8: SRMI_FUSE_K9PW, srmi_epilogue_bwd takes NULL sum pointers; 0.1.7: SRMI_CONV_FUSE_CHAIN + srmi_chain_status + SRMI_ETIMEOUT; 0.1.6: srmi_conv_args.x_copy; 0.1.5: srmi_adam_step takes double hyper-parameters (0.1.4: bn_train_stats counts num_batches_tracked, epilogue_bwd zero-fills the BN-fed bias gradient;
                             srmi_conv2d_kernel_name reports the f32 kernel that runs) */
 
 /* error codes */
@@ -395,6 +395,13 @@ int srmi_bn_train_stats(const float* z, int64_t M, int32_t C, float eps, float m
                         float* running_mean, float* running_var, int64_t* num_batches_tracked, void* ws, void* stream);
 /* (num_batches_tracked, may be NULL: the module's int64 counter, incremented by 1 on the device by the same launch that
  *  updates the running statistics - nn.BatchNorm2d's `self.num_batches_tracked.add_(1)`.) */
+/* The same with the running statistics (and the counter) moved `updates` times, each time rounded to f32 as a forward of
+ * its own would leave them: `updates` = 2 stands for TWO forwards of the module over the same batch with unchanged weights -
+ * the SRGAN iteration runs the generator twice per step (P/mode.py:149 and :164) and the second forward's outputs are the
+ * first's, bit for bit; only BatchNorm's buffers tell the difference.  updates = 0: statistics only. */
+int srmi_bn_train_stats_n(const float* z, int64_t M, int32_t C, float eps, float momentum, float* mean, float* rstd,
+                          float* running_mean, float* running_var, int64_t* num_batches_tracked, int32_t updates, void* ws,
+                          void* stream);
 
 /* y = store(act(bn(z))) + residual.  mean/rstd/gamma/beta are read only when d->bn; residual (shaped like y)
  * may be NULL.  Replaces BatchNorm2d + activation + PixelShuffle + `res += x` (P/ops.py:24-29, :47, :75-83). */

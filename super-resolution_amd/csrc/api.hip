@@ -57,7 +57,7 @@ int y_metrics(const float* sr, const float* gt, int nimg, int H, int W, int gt_H
 
 size_t train_workspace_bytes(int C);
 int bn_train_stats(const float* z, long long M, int C, float eps, float momentum, float* mean, float* rstd,
-                   float* rmean, float* rvar, long long* nbt, void* ws, hipStream_t s);
+                   float* rmean, float* rvar, long long* nbt, int updates, void* ws, hipStream_t s);
 int epilogue_fwd(const srmi_epi_desc& d, const float* z, const float* mean, const float* rstd, const float* gamma,
                  const float* beta, const float* alpha, const float* residual, float* y, hipStream_t s);
 int epilogue_bwd(const srmi_epi_desc& d, const float* z, const float* dy, const float* mean, const float* rstd,
@@ -523,14 +523,20 @@ int srmi_train_workspace_bytes(int32_t C, size_t* bytes) {
     return SRMI_OK;
 }
 
-int srmi_bn_train_stats(const float* z, int64_t M, int32_t C, float eps, float momentum, float* mean, float* rstd,
-                        float* running_mean, float* running_var, int64_t* num_batches_tracked, void* ws, void* stream) {
-    if (!z || !mean || !rstd || !ws || M <= 0 || C <= 0 || (uintptr_t)ws % 8) {
-        set_error("bn_train_stats: bad arguments (M=%lld C=%d)", (long long)M, C);
+int srmi_bn_train_stats_n(const float* z, int64_t M, int32_t C, float eps, float momentum, float* mean, float* rstd,
+                          float* running_mean, float* running_var, int64_t* num_batches_tracked, int32_t updates, void* ws,
+                          void* stream) {
+    if (!z || !mean || !rstd || !ws || M <= 0 || C <= 0 || (uintptr_t)ws % 8 || updates < 0 || updates > 64) {
+        set_error("bn_train_stats: bad arguments (M=%lld C=%d updates=%d)", (long long)M, C, updates);
         return SRMI_EINVAL;
     }
-    return bn_train_stats(z, M, C, eps, momentum, mean, rstd, running_mean, running_var, (long long*)num_batches_tracked, ws,
-                          (hipStream_t)stream);
+    return bn_train_stats(z, M, C, eps, momentum, mean, rstd, running_mean, running_var, (long long*)num_batches_tracked, updates,
+                          ws, (hipStream_t)stream);
+}
+
+int srmi_bn_train_stats(const float* z, int64_t M, int32_t C, float eps, float momentum, float* mean, float* rstd,
+                        float* running_mean, float* running_var, int64_t* num_batches_tracked, void* ws, void* stream) {
+    return srmi_bn_train_stats_n(z, M, C, eps, momentum, mean, rstd, running_mean, running_var, num_batches_tracked, 1, ws, stream);
 }
 
 int srmi_epilogue_fwd(const srmi_epi_desc* d, const float* z, const float* mean, const float* rstd,

@@ -139,9 +139,9 @@ __device__ __forceinline__ void slot_sums(const double* __restrict__ acc, int ns
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ acc, int nslots, long long M, int C,
                                                           float eps, float momentum, float* __restrict__ mean,
                                                           float* __restrict__ rstd, float* __restrict__ rmean,
-                                                          float* __restrict__ rvar, long long* __restrict__ nbt) {
+                                                          float* __restrict__ rvar, long long* __restrict__ nbt, int updates) {
     __shared__ double sh[2][FIN_G][FIN_CH];
-    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += 1;       // nn.BatchNorm2d: num_batches_tracked.add_(1)
+    if (nbt && blockIdx.x == 0 && threadIdx.x == 0) *nbt += updates;  // nn.BatchNorm2d: num_batches_tracked.add_(1), per forward
     const int c = blockIdx.x * FIN_CH + threadIdx.x % FIN_CH, g = threadIdx.x / FIN_CH;
     double t[2];
     slot_sums<2>(acc, nslots, C, c, g, t, sh);
@@ -152,10 +152,18 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     if (var < 0.0) var = 0.0;
     mean[c] = (float)mu;
     rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-    if (rmean) rmean[c] = (float)((1.0 - (double)momentum) * (double)rmean[c] + (double)momentum * mu);
+    // `updates` forwards over the same batch (srmi_bn_train_stats_n): the running statistics move once per forward, each
+    // time rounded to f32 as a forward of its own would leave them
+    if (rmean) {
+        float r = rmean[c];
+        for (int u = 0; u < updates; ++u) r = (float)((1.0 - (double)momentum) * (double)r + (double)momentum * mu);
+        rmean[c] = r;
+    }
     if (rvar) {
         const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
-        rvar[c] = (float)((1.0 - (double)momentum) * (double)rvar[c] + (double)momentum * unbiased);
+        float r = rvar[c];
+        for (int u = 0; u < updates; ++u) r = (float)((1.0 - (double)momentum) * (double)r + (double)momentum * unbiased);
+        rvar[c] = r;
     }
 }
 
@@ -562,7 +570,7 @@ static bool lane_keeps_channels(int C) { return C % 4 == 0 && C >= 4 && 256 % (C
 size_t train_workspace_bytes(int C) { return ((size_t)max_slots(C) * 3 + 3) * C * sizeof(double); }
 
 int bn_train_stats(const float* z, long long M, int C, float eps, float momentum, float* mean, float* rstd,
-                   float* rmean, float* rvar, long long* nbt, void* ws, hipStream_t s) {
+                   float* rmean, float* rvar, long long* nbt, int updates, void* ws, hipStream_t s) {
     const dim3 grid = ch_grid(M, C);      // every slot of the grid is written: nothing to clear
     if (C % 4 == 0 && vec4_ptrs({z}))
         hipLaunchKernelGGL(bn_stats_v4_kernel, grid, dim3(CH_BLOCK), 0, s, z, M, C, (double*)ws);
@@ -571,7 +579,7 @@ int bn_train_stats(const float* z, long long M, int C, float eps, float momentum
     int rc = hip_check(hipGetLastError(), "bn_stats_kernel");
     if (rc) return rc;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, (const double*)ws, (int)grid.x, M, C,
-                       eps, momentum, mean, rstd, rmean, rvar, nbt);
+                       eps, momentum, mean, rstd, rmean, rvar, nbt, updates);
     return hip_check(hipGetLastError(), "bn_finalize_kernel");
 }
 

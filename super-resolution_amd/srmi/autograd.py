@@ -191,6 +191,31 @@ class _PackCache:
 _PACKS = _PackCache()
 
 
+_BN_UPDATES = threading.local()
+
+
+class bn_running_updates:
+    """`with bn_running_updates(2): out = model(x)` - this ONE forward stands for `n` forwards of the same modules over the
+    same batch with unchanged weights: every train-mode BatchNorm moves its running statistics and `num_batches_tracked`
+    n times (srmi_bn_train_stats_n), exactly as n forwards would leave them.  The SRGAN iteration of the reference runs the
+    generator twice per step on the same LR batch (P/mode.py:149 for the discriminator step, :164 for its own step) with
+    no generator update in between: the second forward's outputs are the first's, bit for bit, and only these buffers
+    tell how often it ran."""
+
+    def __init__(self, n):
+        if not 0 <= int(n) <= 64:
+            raise ValueError("bn_running_updates: 0 <= n <= 64")
+        self.n = int(n)
+
+    def __enter__(self):
+        self.prev = getattr(_BN_UPDATES, "n", 1)
+        _BN_UPDATES.n = self.n
+        return self
+
+    def __exit__(self, *exc):
+        _BN_UPDATES.n = self.prev
+
+
 class _Cfg:
     """static (non-tensor) configuration of one fused op"""
 
@@ -254,9 +279,10 @@ class FusedConvFn(torch.autograd.Function):
             if bn.momentum is None:
                 raise NotImplementedError("srmi: BatchNorm2d(momentum=None) (cumulative average) is not supported")
             nbt = bn.num_batches_tracked if track else None      # counted on the device by the finalize launch
-            L.check(lib.srmi_bn_train_stats(z.data_ptr(), M, Cout, float(bn.eps), float(bn.momentum), mean.data_ptr(),
-                                            rstd.data_ptr(), _ptr(bn.running_mean) if track else None,
-                                            _ptr(bn.running_var) if track else None, _ptr(nbt), ws.data_ptr(), st))
+            L.check(lib.srmi_bn_train_stats_n(z.data_ptr(), M, Cout, float(bn.eps), float(bn.momentum), mean.data_ptr(),
+                                              rstd.data_ptr(), _ptr(bn.running_mean) if track else None,
+                                              _ptr(bn.running_var) if track else None, _ptr(nbt),
+                                              getattr(_BN_UPDATES, "n", 1), ws.data_ptr(), st))
         r = cfg.shuffle
         ed = L.EpiDesc(N, Ho, Wo, Cout, cfg.act, cfg.act_param, cfg.apc, r, cfg.order, int(bn is not None))
         y = _empty_cl((N, Cout // (r * r), Ho * r, Wo * r), dev)

@@ -125,6 +125,7 @@ def train(args, images=None, vgg_net=None, log=print):
     import torch.distributed as dist
     import torch.optim.lr_scheduler as lr_scheduler
 
+    from . import autograd as AG
     from . import losses, parallel
     from . import optim          # Adam as ONE launch per model over flat buffers (torch.optim.Adam's update to an ulp)
     from .dataset import Compose, augmentation, crop, mydata
@@ -236,8 +237,14 @@ def train(args, images=None, vgg_net=None, log=print):
             lr = tr_data['LR']
             real_label, fake_label = label(1, lr.shape[0]), label(0, lr.shape[0])
 
-            # Training Discriminator (generator forward #1: BatchNorm running statistics update #1)
-            output, _ = generator(lr)
+            # The reference runs the generator twice per iteration on the same LR batch (P/mode.py:149 and :164) with no
+            # generator update in between: the second forward's outputs are the first's bit for bit.  ONE forward serves
+            # both steps - detached for the discriminator's, with its graph for the generator's own - and BatchNorm's
+            # running statistics move twice, as two forwards leave them (autograd.bn_running_updates).
+            with AG.bn_running_updates(2):
+                output, _ = generator(lr)
+
+            # Training Discriminator
             fake_prob = discriminator(output.detach())
             real_prob = discriminator(gt)
 
@@ -251,8 +258,7 @@ def train(args, images=None, vgg_net=None, log=print):
                 d_loss.backward()
             d_optim.step()
 
-            # Training Generator (generator forward #2 on unchanged weights: running statistics update #2)
-            output, _ = generator(lr)
+            # Training Generator
             with _no_param_grads(discriminator):
                 fake_prob = discriminator(output)
 

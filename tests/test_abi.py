@@ -29,7 +29,7 @@ def test_header_symbols_all_exported():
 
 def test_version_and_struct_layout():
     lib = L.load()
-    assert lib.srmi_version() == 118
+    assert lib.srmi_version() == 119
     assert C.sizeof(L.ConvDesc) == 24 * 4
     assert C.sizeof(L.ConvArgs) == 96 + 7 * 8 + 8 + 8          # ... + flags, reserved + x_copy (ABI 117)
     assert L.ConvArgs.x_copy.offset == 160

@@ -2,7 +2,8 @@
 
 1. The loop's parameters, BatchNorm buffers and losses are BIT-EQUAL to a restatement of the reference loop body that
    keeps the reference's wasted work (generator output not detached in the D step, discriminator weight gradients
-   collected in the G step): the two shortcuts train() takes change no number.
+   collected in the G step, the generator run a SECOND time on the same batch for its own step): the three shortcuts
+   train() takes - one generator forward per iteration, with BatchNorm's running statistics moved twice - change no number.
 2. Cadence: metrics CSV rows every 10 epochs (epoch,psnr,ssim,lpips,dists; NaN for the last two), checkpoints every
    100 pre-train epochs under the reference's file names, loadable into a fresh Generator; the ragged last batch
    (5 images, batch 2) trains."""

@@ -229,6 +229,33 @@ def test_parameters_inside_a_flat_buffer_keep_the_fast_kernels_and_the_bits():
         assert torch.equal(a_, b_)
 
 
+def test_one_forward_standing_for_two_moves_the_running_statistics_twice():
+    """autograd.bn_running_updates(2) (srmi_bn_train_stats_n): output and gradients of ONE forward, BatchNorm buffers as
+    after TWO forwards over the same batch - bit for bit (the SRGAN iteration's two generator forwards, P/mode.py:149, :164)."""
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(3, 64, 10, 14, generator=g).to(DEV)
+    gy = torch.randn(3, 64, 10, 14, generator=g).to(DEV)
+    c2d, act = nn.Conv2d(64, 64, 3, padding=1).to(DEV), nn.PReLU().to(DEV)
+    bn_a, bn_b = nn.BatchNorm2d(64).to(DEV).train(), nn.BatchNorm2d(64).to(DEV).train()
+    with torch.no_grad():
+        for b_ in (bn_a, bn_b):
+            b_.running_mean.copy_(torch.linspace(-1, 1, 64)); b_.running_var.copy_(torch.linspace(0.5, 2, 64))
+    xa = x.clone().requires_grad_(True)
+    AG.fused_conv(xa, c2d, bn_a, act)                      # forward #1 (thrown away, as the reference's is)
+    ya = AG.fused_conv(xa, c2d, bn_a, act)                 # forward #2
+    ya.backward(gy)
+    xb = x.clone().requires_grad_(True)
+    with AG.bn_running_updates(2):
+        yb = AG.fused_conv(xb, c2d, bn_b, act)
+    yb.backward(gy)
+    assert torch.equal(ya, yb) and torch.equal(xa.grad, xb.grad)
+    assert torch.equal(bn_a.running_mean, bn_b.running_mean) and torch.equal(bn_a.running_var, bn_b.running_var)
+    assert int(bn_a.num_batches_tracked) == int(bn_b.num_batches_tracked) == 2
+    with AG.bn_running_updates(0):                         # statistics only: buffers untouched
+        AG.fused_conv(xb.detach(), c2d, bn_b, act)
+    assert torch.equal(bn_a.running_var, bn_b.running_var) and int(bn_b.num_batches_tracked) == 2
+
+
 # (3,8,3,3,10): gathering dgrad + MFMA wgrad; the others take the full-map forms (dgrad as a forward GEMM with the
 # [co][tap][ci] operand, the outer-product wgrad through the transposed x) and, at 256 outputs, the tiled forward pack
 @pytest.mark.parametrize("shape", [(3, 8, 3, 3, 10), (5, 128, 6, 6, 40), (4, 128, 6, 6, 256), (16, 32, 12, 12, 64),

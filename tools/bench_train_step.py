@@ -68,8 +68,13 @@ def build_step(dev, B=16, L=24, rank=0, overlap=True, literal=False, torch_adam=
     # every parameter, buffer and loss): the generator output is detached for the D step and D's parameters collect no
     # gradients in the G step - the reference computes both and throws them away (P/mode.py:149-160, :165-178; SURVEY 3.3
     # "minimal necessary work").  `literal=True` keeps the wasted work.
+    from srmi import autograd as AG
+
     def step():
-        output, _ = generator(lr)
+        # (srmi.mode.train: ONE generator forward per iteration - the reference's second one, P/mode.py:164, repeats the first
+        #  bit for bit; BatchNorm's running statistics move twice)
+        with AG.bn_running_updates(1 if literal else 2):
+            output, _ = generator(lr)
         fake_prob = discriminator(output if literal else output.detach())
         real_prob = discriminator(gt)
         d_loss = cross_ent(real_prob, real_label) + cross_ent(fake_prob, fake_label)
@@ -81,7 +86,8 @@ def build_step(dev, B=16, L=24, rank=0, overlap=True, literal=False, torch_adam=
             d_loss.backward()
             parallel.average_gradients(discriminator.parameters())
         d_optim.step()
-        output, _ = generator(lr)
+        if literal:
+            output, _ = generator(lr)
         with (contextlib.nullcontext() if literal else _no_param_grads(discriminator)):
             fake_prob = discriminator(output)
             _percep, hr_feat, sr_feat = VGG_loss((gt + 1.0) / 2.0, (output + 1.0) / 2.0, layer="relu5_4")
@@ -147,8 +153,9 @@ def cfg3(steps=10, warmup=3, B=16, L=24, dev=None, dist=None, rank=0, world=1, o
                       "optimizer": "torch.optim.Adam (foreach)" if torch_adam else "srmi.optim.Adam (flat buffers, one launch per model)",
                       "gradient_exchange": "overlapped (GradientAverager.sync)" if overlap else "after backward",
                       "iteration": "reference-literal (wasted G backward in the D step and D weight gradients in the G step kept)"
-                                   if literal else "as srmi.mode.train: G output detached for the D step, no D weight gradients in "
-                                   "the G step (bit-equal results, tests/test_mode_train_gpu.py)"},
+                                   if literal else "as srmi.mode.train: one G forward per iteration (the reference's second repeats the first bit "
+                                   "for bit; BN running statistics moved twice), detached for the D step, no D weight gradients "
+                                   "in the G step (bit-equal results, tests/test_mode_train_gpu.py)"},
            "d_loss": round(float(d_loss.detach()), 5), "g_loss": round(float(g_loss.detach()), 5)}
     if B == 16 and L == 24:
         tf = MIN_STEP_TFLOP / (ms * 1e-3)
