@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define SRMI_VERSION 119 /* 0.1.9: srmi_bn_train_stats_n; 0.1.8: SRMI_FUSE_K9PW, srmi_epilogue_bwd takes NULL sum pointers; 0.1.7: SRMI_CONV_FUSE_CHAIN + srmi_chain_status + SRMI_ETIMEOUT; 0.1.6: srmi_conv_args.x_copy; 0.1.5: srmi_adam_step takes double hyper-parameters (0.1.4: bn_train_stats counts num_batches_tracked, epilogue_bwd zero-fills the BN-fed bias gradient;
+#define SRMI_VERSION 119 /* 0.1.9: srmi_bn_train_stats_n, srmi_conv2d_fwd_bn_stats; 0.1.8: SRMI_FUSE_K9PW, srmi_epilogue_bwd takes NULL sum pointers; 0.1.7: SRMI_CONV_FUSE_CHAIN + srmi_chain_status + SRMI_ETIMEOUT; 0.1.6: srmi_conv_args.x_copy; 0.1.5: srmi_adam_step takes double hyper-parameters (0.1.4: bn_train_stats counts num_batches_tracked, epilogue_bwd zero-fills the BN-fed bias gradient;
                             srmi_conv2d_kernel_name reports the f32 kernel that runs) */
 
 /* error codes */
@@ -402,6 +402,18 @@ int srmi_bn_train_stats(const float* z, int64_t M, int32_t C, float eps, float m
 int srmi_bn_train_stats_n(const float* z, int64_t M, int32_t C, float eps, float momentum, float* mean, float* rstd,
                           float* running_mean, float* running_var, int64_t* num_batches_tracked, int32_t updates, void* ws,
                           void* stream);
+
+/* srmi_conv2d_fwd_ws(a, conv_ws, conv_ws_bytes) followed by srmi_bn_train_stats_n on its output, as ONE call - and, where
+ * the conv runs on the halo-tile split kernel ("b3h_f32": the generator's 64 -> 64 body convs) with at most as many tiles as the
+ * statistics workspace has slots, as one pass: every workgroup leaves the per-channel sum and sum of squares of the 64
+ * output pixels it has just computed in its own slot (f64, fixed order), and only the small finalize launch follows - no
+ * second read of the conv output, one launch fewer per conv + BatchNorm (P/ops.py:22-26 under P/mode.py:101).  `a` must
+ * describe z = conv + shift: dense NHWC f32 output, no scale / activation / residual / sub-pixel store.  stat_ws as for
+ * srmi_bn_train_stats (srmi_train_workspace_bytes(Cout)).  Deterministic; the two forms sum in different orders, so mean /
+ * rstd may differ in the last bit between a fused and an unfused shape. */
+int srmi_conv2d_fwd_bn_stats(const srmi_conv_args* a, void* conv_ws, size_t conv_ws_bytes, float eps, float momentum,
+                             float* mean, float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                             int32_t updates, void* stat_ws, void* stream);
 
 /* y = store(act(bn(z))) + residual.  mean/rstd/gamma/beta are read only when d->bn; residual (shaped like y)
  * may be NULL.  Replaces BatchNorm2d + activation + PixelShuffle + `res += x` (P/ops.py:24-29, :47, :75-83). */

@@ -56,6 +56,9 @@ int y_metrics(const float* sr, const float* gt, int nimg, int H, int W, int gt_H
               int win, double* out, void* ws, hipStream_t s);
 
 size_t train_workspace_bytes(int C);
+int train_max_slots(int C);
+int bn_finalize_launch(const void* ws, int nslots, long long M, int C, float eps, float momentum, float* mean, float* rstd,
+                       float* rmean, float* rvar, long long* nbt, int updates, hipStream_t s);
 int bn_train_stats(const float* z, long long M, int C, float eps, float momentum, float* mean, float* rstd,
                    float* rmean, float* rvar, long long* nbt, int updates, void* ws, hipStream_t s);
 int epilogue_fwd(const srmi_epi_desc& d, const float* z, const float* mean, const float* rstd, const float* gamma,
@@ -532,6 +535,40 @@ int srmi_bn_train_stats_n(const float* z, int64_t M, int32_t C, float eps, float
     }
     return bn_train_stats(z, M, C, eps, momentum, mean, rstd, running_mean, running_var, (long long*)num_batches_tracked, updates,
                           ws, (hipStream_t)stream);
+}
+
+int srmi_conv2d_fwd_bn_stats(const srmi_conv_args* a, void* conv_ws, size_t conv_ws_bytes, float eps, float momentum,
+                             float* mean, float* rstd, float* running_mean, float* running_var, int64_t* num_batches_tracked,
+                             int32_t updates, void* stat_ws, void* stream) {
+    if (!a || !mean || !rstd || !stat_ws || (uintptr_t)stat_ws % 8 || updates < 0 || updates > 64) {
+        set_error("conv2d_fwd_bn_stats: bad arguments");
+        return SRMI_EINVAL;
+    }
+    if (conv_ws && ((uintptr_t)conv_ws & 15)) { set_error("conv2d_fwd_bn_stats: workspace must be 16-byte aligned"); return SRMI_EINVAL; }
+    const srmi_conv_desc& d = a->d;
+    ConvGeom g;
+    int rc = conv_geom(d, &g);
+    if (rc) return rc;
+    const long long M = (long long)d.N * g.Ho * g.Wo;
+    if (d.out_layout != SRMI_NHWC || d.out_dtype != SRMI_F32 || d.shuffle != 1 || d.out_coffset != 0 ||
+        (d.out_cstride && d.out_cstride != d.Cout) || d.act != SRMI_ACT_NONE || a->residual || a->scale || M <= 0) {
+        set_error("conv2d_fwd_bn_stats: the conv must write its dense NHWC f32 output z = conv + shift (no scale, activation, "
+                  "residual or sub-pixel store) over a non-empty batch");
+        return SRMI_EUNSUPPORTED;
+    }
+    // the halo-tile split kernel leaves per-workgroup sums of its own output in the statistics slots (one slot per tile)
+    const long long tiles = b3h_tiles(d);
+    const bool fused = select_kernel(d) == K_GENERIC_F32 && b3h_fwd_ok(d) && tiles <= train_max_slots(d.Cout) && a->x && a->w && a->y;
+    if (fused) {
+        rc = generic_launch(*a, g, (hipStream_t)stream, conv_ws, conv_ws_bytes, (double*)stat_ws);
+        if (rc) return rc;
+        return bn_finalize_launch(stat_ws, (int)tiles, M, d.Cout, eps, momentum, mean, rstd, running_mean, running_var,
+                                  (long long*)num_batches_tracked, updates, (hipStream_t)stream);
+    }
+    rc = conv_fwd_one(a, (hipStream_t)stream, conv_ws, conv_ws_bytes);
+    if (rc) return rc;
+    return bn_train_stats((const float*)a->y, M, d.Cout, eps, momentum, mean, rstd, running_mean, running_var,
+                          (long long*)num_batches_tracked, updates, stat_ws, (hipStream_t)stream);
 }
 
 int srmi_bn_train_stats(const float* z, int64_t M, int32_t C, float eps, float momentum, float* mean, float* rstd,

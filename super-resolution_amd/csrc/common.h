@@ -92,7 +92,10 @@ int select_kernel(const srmi_conv_desc& d);
 // generic f32-MFMA kernel (conv_generic.hip)
 size_t generic_packed_bytes(const srmi_conv_desc& d);
 int generic_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipStream_t s);
-int generic_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s, void* ws = nullptr, size_t ws_bytes = 0);
+int generic_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s, void* ws = nullptr, size_t ws_bytes = 0,
+                   double* bn_stats = nullptr);
+long long b3h_tiles(const srmi_conv_desc& d);          // conv_b3h_f32.hip: its workgroups along x = statistics slots
+bool b3h_fwd_ok(const srmi_conv_desc& d);
 size_t generic_workspace_bytes(const srmi_conv_desc& d, const ConvGeom& g);
 const char* generic_kernel_label(const srmi_conv_desc& d, const ConvGeom& g);   // which f32 kernel runs d: b3h_f32 | b3_f32 | f32t | generic_f32
 

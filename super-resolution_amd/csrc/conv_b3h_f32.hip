@@ -44,10 +44,14 @@ struct B3hParams {
     int tiles_x, tiles_y;
     int transposed;
     const float* alpha; int act, alpha_pc; float act_param;      // slope activations (none / ReLU / LeakyReLU / PReLU)
+    double* stats;      // NULL, or per-workgroup partial sums of the OUTPUT for train-mode BatchNorm (train.hip's slot
+                        // layout: slot = tile index, [slot][2][Cout]: sum, sum of squares): the statistics pass that
+                        // would re-read the whole output comes for free in the epilogue (act must be NONE)
 };
 
 __global__ __launch_bounds__(256) void conv_b3h_kernel(B3hParams p) {
     __shared__ __attribute__((aligned(16))) unsigned short As[3][B3H_HS * B3H_ROWP];
+    __shared__ double bnsum[2][2][2][32];                   // [wm][wn][sum, sum of squares][channel of the wave's tile]
     auto at = [](int hy, int hx) { return hy * B3H_ROWP + hx * B3H_PITCH; };      // element offset of halo pixel (hy, hx) in a plane
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -140,6 +144,7 @@ __global__ __launch_bounds__(256) void conv_b3h_kernel(B3hParams p) {
     // slope of the negative side, as generic_epilogue_flat applies it (1: no activation)
     const float sl = p.act == SRMI_ACT_PRELU ? p.alpha[p.alpha_pc ? co : 0] : p.act == SRMI_ACT_LRELU ? p.act_param
                    : p.act == SRMI_ACT_RELU ? 0.f : 1.f;
+    double s1 = 0.0, s2 = 0.0;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
         const int q = 32 * wm + (e & 3) + 8 * (e >> 2) + 4 * h;
@@ -150,6 +155,18 @@ __global__ __launch_bounds__(256) void conv_b3h_kernel(B3hParams p) {
             v = v >= 0.f ? v : v * sl;
             if (p.res) v += p.res[pix * p.res_cs + co];
             p.y[pix * p.out_cs + p.out_co + co] = v;
+            if (p.stats) { s1 += (double)v; s2 += (double)v * (double)v; }
+        }
+    }
+    if (p.stats) {      // (wave-uniform) sums of this workgroup's 64 pixels per channel, in a fixed order: rows, h, wm
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (h == 0) { bnsum[wm][wn][0][i] = s1; bnsum[wm][wn][1][i] = s2; }
+        __syncthreads();
+        if (tid < 128) {
+            const int k = tid >> 6, w2 = (tid >> 5) & 1, c = tid & 31;
+            const int ch = 32 * (blockIdx.y * 2 + w2) + c;
+            p.stats[((size_t)blockIdx.x * 2 + k) * p.Cout + ch] = bnsum[0][w2][k][c] + bnsum[1][w2][k][c];
         }
     }
 }
@@ -201,6 +218,11 @@ bool b3h_dgrad_ok(const srmi_conv_desc& d) {
            d.Cin / 64 <= 65535;
 }
 
+// workgroups along x (= partial-sum slots of the fused BatchNorm statistics) for the forward conv of `d`
+long long b3h_tiles(const srmi_conv_desc& d) {
+    return (long long)d.N * ((d.H + B3H_T - 1) / B3H_T) * ((d.W + B3H_T - 1) / B3H_T);
+}
+
 size_t b3h_packed_bytes(const srmi_conv_desc& d) { return (size_t)3 * 9 * d.Cin * d.Cout * sizeof(unsigned short); }
 
 int b3h_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, int transposed, hipStream_t s) {
@@ -230,6 +252,7 @@ int b3h_launch(const GenericParams& g) {
     p.tiles_x = (p.W + B3H_T - 1) / B3H_T; p.tiles_y = (p.H + B3H_T - 1) / B3H_T;
     p.transposed = g.transposed;
     p.alpha = g.alpha; p.act = g.act; p.alpha_pc = g.alpha_pc; p.act_param = g.act_param;
+    p.stats = g.bn_stats;
     const long long tiles = (long long)p.tiles_x * p.tiles_y * p.N;
     if (tiles <= 0) return SRMI_OK;
     if (tiles > 0x7fffffffLL) { set_error("conv (split-bf16 3x3 kernel): too many tiles"); return SRMI_EINVAL; }

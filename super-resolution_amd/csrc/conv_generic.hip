@@ -382,10 +382,12 @@ size_t generic_workspace_bytes(const srmi_conv_desc& d, const ConvGeom& g) {
     return ks > 1 ? (size_t)ks * d.N * g.Cf * g.Hf * g.Wf * sizeof(float) : 0;
 }
 
-int generic_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s, void* ws, size_t ws_bytes) {
+int generic_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s, void* ws, size_t ws_bytes, double* bn_stats) {
     const srmi_conv_desc& d = a.d;
     GenericParams p;
     generic_fill(p, a, g);
+    if (bn_stats && p.b3 != 2) { set_error("conv: fused BN statistics are served by the halo-tile split kernel only"); return SRMI_EUNSUPPORTED; }
+    p.bn_stats = bn_stats;
     p.stream = s;
     p.partial = (float*)ws;
     p.partial_stride = ws ? ws_bytes / sizeof(float) : 0;     // capacity in elements until generic_run fixes the stride

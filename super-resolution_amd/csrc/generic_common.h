@@ -21,6 +21,7 @@ struct GenericParams {
     int dbg;         // ablation switches of the tiled kernel (SRMI_DBG bits 26..29; investigation only, 0 = product path)
     unsigned wo_mul, ho_mul; int wo_sh, ho_sh;   // tiled kernel: multiply-shift division by Wo / Ho (f32t_magic)
     int b3;          // the operand is in conv_b3_f32.hip's split-bf16 format: that kernel runs
+    double* bn_stats;  // conv_b3h_kernel only: per-workgroup sum / sum of squares of the output (train-mode BN statistics)
 };
 
 

@@ -567,6 +567,16 @@ static bool vec4_ptrs(std::initializer_list<const void*> ps) {
 // four channels per lane with loop-invariant channels: C / 4 divides the 256-thread workgroup
 static bool lane_keeps_channels(int C) { return C % 4 == 0 && C >= 4 && 256 % (C / 4) == 0; }
 
+int train_max_slots(int C) { return max_slots(C); }
+
+// partial slots [nslots][2][C] (sum, sum of squares) -> mean / rstd / running statistics (the second half of bn_train_stats)
+int bn_finalize_launch(const void* ws, int nslots, long long M, int C, float eps, float momentum, float* mean, float* rstd,
+                       float* rmean, float* rvar, long long* nbt, int updates, hipStream_t s) {
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + FIN_CH - 1) / FIN_CH), dim3(256), 0, s, (const double*)ws, nslots, M, C,
+                       eps, momentum, mean, rstd, rmean, rvar, nbt, updates);
+    return hip_check(hipGetLastError(), "bn_finalize_kernel");
+}
+
 size_t train_workspace_bytes(int C) { return ((size_t)max_slots(C) * 3 + 3) * C * sizeof(double); }
 
 int bn_train_stats(const float* z, long long M, int C, float eps, float momentum, float* mean, float* rstd,

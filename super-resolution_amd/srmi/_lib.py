@@ -122,6 +122,8 @@ SYMBOLS = {
     "srmi_train_workspace_bytes": (C.c_int, [C.c_int32, C.POINTER(C.c_size_t)]),
     "srmi_bn_train_stats": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                       C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "srmi_conv2d_fwd_bn_stats": (C.c_int, [C.POINTER(ConvArgs), C.c_void_p, C.c_size_t, C.c_float, C.c_float, C.c_void_p,
+                                           C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "srmi_bn_train_stats_n": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_float, C.c_float, C.c_void_p, C.c_void_p,
                                         C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]),
     "srmi_epilogue_fwd": (C.c_int, [C.POINTER(EpiDesc)] + [C.c_void_p] * 9),

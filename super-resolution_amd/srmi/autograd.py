@@ -265,11 +265,11 @@ class FusedConvFn(torch.autograd.Function):
         a = L.ConvArgs()
         Fn.fill_args(a, desc, x, wp, None, shift, None, None, z)
         wsk = _WS.get(plan.ws_fwd, dev)
-        L.check(lib.srmi_conv2d_fwd_ws(C.byref(a), _ptr(wsk), plan.ws_fwd, st))
-
         mean = rstd = None
         M = N * Ho * Wo
-        if bn is not None:
+        if bn is None:
+            L.check(lib.srmi_conv2d_fwd_ws(C.byref(a), _ptr(wsk), plan.ws_fwd, st))
+        else:
             if M == 0:
                 raise ValueError("srmi: train-mode BatchNorm over an empty batch")
             mean = torch.empty(Cout, dtype=torch.float32, device=dev)
@@ -279,10 +279,12 @@ class FusedConvFn(torch.autograd.Function):
             if bn.momentum is None:
                 raise NotImplementedError("srmi: BatchNorm2d(momentum=None) (cumulative average) is not supported")
             nbt = bn.num_batches_tracked if track else None      # counted on the device by the finalize launch
-            L.check(lib.srmi_bn_train_stats_n(z.data_ptr(), M, Cout, float(bn.eps), float(bn.momentum), mean.data_ptr(),
-                                              rstd.data_ptr(), _ptr(bn.running_mean) if track else None,
-                                              _ptr(bn.running_var) if track else None, _ptr(nbt),
-                                              getattr(_BN_UPDATES, "n", 1), ws.data_ptr(), st))
+            # conv + batch statistics in one native call; where the conv runs on the halo-tile kernel (the generator's body
+            # convs) its epilogue leaves the per-workgroup sums behind and no statistics pass reads z again
+            L.check(lib.srmi_conv2d_fwd_bn_stats(C.byref(a), _ptr(wsk), plan.ws_fwd, float(bn.eps), float(bn.momentum),
+                                                 mean.data_ptr(), rstd.data_ptr(), _ptr(bn.running_mean) if track else None,
+                                                 _ptr(bn.running_var) if track else None, _ptr(nbt),
+                                                 getattr(_BN_UPDATES, "n", 1), ws.data_ptr(), st))
         r = cfg.shuffle
         ed = L.EpiDesc(N, Ho, Wo, Cout, cfg.act, cfg.act_param, cfg.apc, r, cfg.order, int(bn is not None))
         y = _empty_cl((N, Cout // (r * r), Ho * r, Wo * r), dev)
