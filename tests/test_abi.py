@@ -134,3 +134,13 @@ def test_add_relu_kernel_selection():
     d = Fn.make_desc(2, 16, 16, 64, 64, 3, act=L.ACT_ADD_RELU + 1)
     n = C.c_size_t(0)
     assert L.load().srmi_conv2d_packed_weight_bytes(C.byref(d), C.byref(n)) != 0
+
+
+def test_graft_entry_build_runs():
+    """__graft_entry__.build(): make (up to date after the first run), library loads, version = include/srmi.h, every symbol."""
+    import importlib
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    importlib.import_module("__graft_entry__").build()
