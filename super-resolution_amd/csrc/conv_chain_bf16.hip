@@ -901,7 +901,7 @@ static bool chain_wide_ok(const srmi_conv_args* a, int nprev, const srmi_conv_ar
 static bool chain_head_ok(const srmi_conv_args& h, const srmi_conv_args& first) {
     const srmi_conv_desc& d = h.d;
     if (!(h.flags & SRMI_CONV_FUSE_CHAIN) || (h.flags & SRMI_CONV_FUSE_NEXT) || h.x_copy || h.residual) return false;
-    if (!k9c3_supported(d) || select_kernel(d) != K_K9C3_BF16 || d.Cout != 64) return false;      // (packed-weight format = the kernel's)
+    if (!k9c3_supported(d) || select_kernel(d) != K_K9C3_BF16 || d.Cout != 64 || d.kh != 9) return false;      // (packed-weight format = the 9x9 kernel's)
     if (d.N != first.d.N || d.H != first.d.H || d.W != first.d.W) return false;
     if ((d.out_cstride && d.out_cstride != 64) || d.out_coffset) return false;
     if (!h.x || !h.w || !h.y || !h.scale || !h.shift || h.y != first.x) return false;

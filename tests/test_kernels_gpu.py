@@ -315,23 +315,28 @@ def test_c64_thin_kernel(case):
     dict(N=1, H=20, W=33, in_layout=L.NHWC),                # NHWC f32 input
     dict(N=1, H=8, W=40, in_layout=L.NHWC, Cin=1, alpha_pc=1),          # single-channel input (Y only), per-channel slopes
     dict(N=1, H=10, W=70, in_layout=L.NCHW, Cin=1, Cout=128, alpha_pc=1),   # SRCNN conv1 (SRCNN/srcnn.py:203): two 64-ch launches
+    # 3x3 taps on the same kernel (KS = 3): the RRDB generator's head conv (ESRGAN/untitled0.py:41), D / VGG19 conv 1
+    dict(N=2, H=9, W=7, in_layout=L.NCHW, k=3),
+    dict(N=1, H=13, W=100, in_layout=L.NCHW, k=3),
+    dict(N=1, H=20, W=33, in_layout=L.NHWC, k=3, Cin=2),
+    dict(N=1, H=8, W=40, in_layout=L.NCHW, k=3, Cin=1, Cout=128, alpha_pc=1),
 ])
 def test_k9c3_kernel(case):
-    """conv01: 9x9, Cin<=3 -> 64, PReLU, f32 NCHW/NHWC in -> NHWC bf16 out."""
+    """conv01: 9x9 (or 3x3), Cin<=3 -> 64, PReLU, f32 NCHW/NHWC in -> NHWC bf16 out."""
     g = _rng(4)
     N, H, W, Cin = case["N"], case["H"], case["W"], case.get("Cin", 3)
-    Cout, apc = case.get("Cout", 64), case.get("alpha_pc", 0)
+    Cout, apc, k = case.get("Cout", 64), case.get("alpha_pc", 0), case.get("k", 9)
     x = torch.from_numpy(g.uniform(-1, 1, (N, Cin, H, W)).astype(np.float32))
-    w = torch.from_numpy((g.standard_normal((Cout, Cin, 9, 9)) / np.sqrt(81.0 * Cin)).astype(np.float32))
+    w = torch.from_numpy((g.standard_normal((Cout, Cin, k, k)) / np.sqrt(float(k * k) * Cin)).astype(np.float32))
     scale = torch.from_numpy(g.uniform(0.5, 1.5, Cout).astype(np.float32))
     shift = torch.from_numpy(g.uniform(-0.3, 0.3, Cout).astype(np.float32))
     alpha = torch.from_numpy(g.uniform(0.05, 0.4, Cout).astype(np.float32)) if apc else torch.tensor([0.25])
     # the kernel rounds x and w to bf16 before the MFMA: so does the reference
-    ref = _ref_fused(x.bfloat16().float(), w.bfloat16().float(), scale, shift, L.ACT_PRELU, 0.0, alpha, None, 1, 4, 1, False)
-    desc = Fn.make_desc(N, H, W, Cin, Cout, 9, in_dtype=L.F32, out_dtype=L.BF16, in_layout=case["in_layout"],
+    ref = _ref_fused(x.bfloat16().float(), w.bfloat16().float(), scale, shift, L.ACT_PRELU, 0.0, alpha, None, 1, k // 2, 1, False)
+    desc = Fn.make_desc(N, H, W, Cin, Cout, k, in_dtype=L.F32, out_dtype=L.BF16, in_layout=case["in_layout"],
                         compute=L.COMPUTE_BF16, act=L.ACT_PRELU, alpha_per_channel=apc)
-    # (one input channel with a scalar slope is the dense-tap kernel's shape)
-    assert L.kernel_name(desc) == ("k9c1_bf16" if Cin == 1 and not apc else "k9c3_bf16")
+    # (one input channel with a scalar slope and 9x9 taps is the dense-tap kernel's shape)
+    assert L.kernel_name(desc) == ("k9c1_bf16" if Cin == 1 and not apc and k == 9 else "k9c3_bf16")
     xd = (x if case["in_layout"] == L.NCHW else x.permute(0, 2, 3, 1).contiguous()).to(DEV)
     wp = Fn.pack_weights(desc, w.to(DEV))
     y = Fn.conv2d_fused(desc, xd, wp, scale.to(DEV), shift.to(DEV), alpha.to(DEV))
