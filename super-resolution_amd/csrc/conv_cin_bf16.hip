@@ -17,6 +17,8 @@
 // generic f32 kernel's.
 #include <stdlib.h>
 
+#include <atomic>
+
 #include <type_traits>
 
 #include "c64_common.h"
@@ -30,6 +32,7 @@ struct CinParams {
     int N, H, W, Cin, Cout, kchunks, in_cs, out_cs, out_co, res_cs;
     int act; float act_param; int alpha_pc;
     int tiles_x, tiles_y;
+    int exp;           // ablation build only (SRMI_EXP): 0 in the product library
 };
 
 constexpr int CIN_WRING = 4;
@@ -285,6 +288,333 @@ __global__ __launch_bounds__(NW * 64, WGPC) void conv_cin_kernel(CinParams p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Persistent, software-pipelined form for layers with many tiles (the RRDB dense / compress convs at 8 x 256 x 256,
+// SRCNN's 128 -> 64 at 32 x 384 x 384).  In the kernel above every workgroup stages a chunk, waits for it, computes, stages
+// the next: all workgroups of a round do so in step, so HBM idles while the matrix cores run and the other way round
+// (rocprofv3: 2.4-3.1 TB/s of traffic AND 0.20-0.35 MFMA-pipe busy, profiles/r3_cfg4_layers.json).  Here one workgroup
+// per CU walks through its tiles with the work split over SPECIALISED waves:
+//   waves 0-3  (consumers) : LDS reads, MFMAs, the epilogue and its stores - no vector-memory wait anywhere;
+//   wave 4     (tile mover): LDS-DMA of the NEXT stage's halo tile (stage = one 64-channel chunk of one 8 x 32 tile,
+//                            50 pieces of 1 KiB, swizzle applied on the source side, borders / padded channels read from
+//                            a zero line) into the other tile buffer while the consumers work; vmcnt(0) once per stage;
+//   wave 5     (tap mover) : the 4-slot weight ring of the kernel above (tap g + 3 issued when tap g - 1 is retired, a
+//                            counted vmcnt per tap), as its own in-order stream.
+// Three streams because vmcnt retires in order per wave: taps (needed three steps later) queued behind a tile (needed a
+// stage later, a full HBM latency) would wait for it.  Every wave executes the same barriers: one per stage (the tile
+// of the stage has landed / the previous stage's buffer is free) and one per tap (as above).  All loops are counted:
+// no wave waits on another workgroup.  Arithmetic and order of summation are those of conv_cin_kernel: same bits.
+constexpr int CINP_TH = 8, CINP_TW = 32, CINP_ROWP = 40;
+constexpr int CINP_IN_BYTES = (CINP_TH + 2) * CINP_ROWP * 128;      // 51200 = 10 rows x 5 DMA pieces of 1 KiB
+constexpr int cinp_ring(int nct) { return nct == 2 ? 8 : 6; }      // weight ring slots (LDS: 136 KB / 152 KB per workgroup)
+
+template <int NCT>
+__global__ __launch_bounds__(512, 1) void conv_cinp_kernel(CinParams p, int ntiles) {
+    constexpr int TH = CINP_TH, TW = CINP_TW, TWT = 2, ROWP = CINP_ROWP, PT = 4;
+    constexpr int IN_BYTES = CINP_IN_BYTES;
+    constexpr int TAP_BYTES = 2 * NCT * 1024;
+    constexpr int NDMAW = TAP_BYTES / 2048;            // LDS-DMA instructions per tap and tap mover (two waves move a tap)
+    constexpr int R = cinp_ring(NCT);
+    constexpr int CG = NCT * 16;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * IN_BYTES + R * TAP_BYTES + 3 * 64 * 4];
+    unsigned char* const wring = lds + 2 * IN_BYTES;
+    float* const par = (float*)(lds + 2 * IN_BYTES + R * TAP_BYTES);
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+    // tiles of this workgroup: XCD x = blockIdx.x & 7 owns a contiguous range of tiles, its CUs take them round robin,
+    // so the 32 CUs of an XCD work on 32 neighbouring tiles at any time (halos meet in that XCD's L2)
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3, nslot = gridDim.x >> 3;
+    const int per_xcd = (ntiles + 7) >> 3;
+    const int mine = min(per_xcd, ntiles - xcd * per_xcd) - slot;       // tiles xcd * per_xcd + slot + it * nslot, it >= 0
+    if (mine <= 0) return;
+    const int ntl = (mine + nslot - 1) / nslot;
+    const int KC = p.kchunks;
+    const int nstage = ntl * KC;
+    const int cg = blockIdx.y;
+    const int tile0 = xcd * per_xcd + slot;
+
+    if (wave == 4 || wave == 5) {
+        // ================================ tile movers (rows 0-4 / 5-9 of the halo tile) ================================
+        const int r0 = (wave - 4) * 5;
+        // buffer loads with the LDS as destination: lanes outside the image (or past the chunk's real channels) carry an
+        // offset beyond the resource and read zeros - the padding of the conv and of a half chunk
+        const int pos = lane & 7, sub = lane >> 3;
+        const int ch = pos ^ c64_key(sub);              // c64_key(8 * piece + sub) = c64_key(sub): position pos holds chunk ch
+        __amdgpu_buffer_rsrc_t rs;
+        unsigned lanebase[5];
+        int y0 = 0, rowpitch = p.W * p.in_cs * 2;
+        unsigned char* dstbuf = lds;
+        auto setup = [&](int s) {
+            const int it = s / KC, kc = s - it * KC;
+            int b = tile0 + it * nslot;
+            const int tx = b % p.tiles_x; b /= p.tiles_x;
+            const int ty = b % p.tiles_y;
+            const int n = b / p.tiles_y;
+            y0 = ty * TH - 1;
+            const int x0 = tx * TW - 1;
+            const int cvalid = min(p.Cin - kc * 64, 64) >> 3;
+            rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.x + (size_t)n * p.H * p.W * p.in_cs + kc * 64), 0,
+                                                   p.H * rowpitch - kc * 128, 0x00020000);
+            dstbuf = lds + (s & 1) * IN_BYTES;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int col = 8 * j + sub, gx = x0 + col;
+                const bool ok = col < TW + 2 && gx >= 0 && gx < p.W && ch < cvalid;
+                lanebase[j] = ok ? (unsigned)((gx * p.in_cs + ch * 8) * 2) : 0x80000000u;
+            }
+        };
+        auto issue_row = [&](int r) {
+#ifdef SRMI_ABLATE
+            if (p.exp & (1 << 21)) return;
+#endif
+            const int gy = y0 + r;
+            const bool rowok = gy >= 0 && gy < p.H;
+            const unsigned rowoff = rowok ? (unsigned)(gy * rowpitch) : 0x80000000u;
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const unsigned voff = rowok ? lanebase[j] + rowoff : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lptr_t)(dstbuf + (r * 5 + j) * 1024), 16, voff, 0, 0, 0);
+            }
+        };
+        setup(0);
+        for (int r = 0; r < 5; ++r) issue_row(r0 + r);
+        for (int s = 0; s < nstage; ++s) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // stage s has landed
+            __builtin_amdgcn_s_barrier();                            // ... and the consumers are done with stage s - 1
+            const bool more = s + 1 < nstage;
+            // the whole next tile is requested within the first three tap steps (a stage of lead: what is in flight per CU
+            // over the memory latency is the bandwidth the pipeline can draw), in slices so as not to be late at a barrier
+            if (more) { setup(s + 1); issue_row(r0); issue_row(r0 + 1); }
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                __builtin_amdgcn_s_barrier();
+                if (more && t < 3) issue_row(r0 + 2 + t);
+            }
+        }
+        return;
+    }
+
+    if (wave >= 6) {
+        // ================================ tap movers (each one half of every tap) ================================
+        const int ntap = nstage * 9;
+        const unsigned char* wbase = (const unsigned char*)p.w + (size_t)cg * KC * 9 * TAP_BYTES + (wave - 6) * (TAP_BYTES / 2) + lane * 16;
+        const unsigned wring_lds = (unsigned)(uintptr_t)(lptr_t)wring + (unsigned)((wave - 6) * (TAP_BYTES / 2));
+        int islot = 0, is = 0, itap = 0;                             // ring slot / stage / tap of the next tap to issue
+        auto issue_next = [&]() {
+#ifdef SRMI_ABLATE
+            if (p.exp & (1 << 22)) return;
+#endif
+            const int kc = is % KC;
+            const unsigned char* src = wbase + (size_t)(kc * 9 + itap) * TAP_BYTES;
+            const unsigned dst = __builtin_amdgcn_readfirstlane(wring_lds + (unsigned)(islot * TAP_BYTES));
+#pragma unroll
+            for (int i = 0; i < NDMAW; ++i) {
+                unsigned keep;
+                asm volatile(
+                    "s_mov_b32 %0, m0\n\t"
+                    "s_mov_b32 m0, %2\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %1, off\n\t"
+                    "s_mov_b32 m0, %0"
+                    : "=&s"(keep)
+                    : "v"(src + i * 1024), "s"(dst + (unsigned)(i * 1024))
+                    : "memory");
+            }
+            if (++islot == R) islot = 0;
+            if (++itap == 9) { itap = 0; ++is; }
+        };
+        // taps 0 .. R-2 up front (ntap >= 9 > R - 2); tap g + R - 1 follows when tap g - 1 is retired
+        for (int i = 0; i < R - 1; ++i) issue_next();
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * NDMAW) : "memory");     // tap 0 landed
+        int g = 0;
+        for (int s = 0; s < nstage; ++s) {
+            __builtin_amdgcn_s_barrier();
+            for (int t = 0; t < 9; ++t, ++g) {
+                // tap g + 1 landed; the taps issued after it (at most R - 3, fewer at the end of the stream) may stay in flight
+                const int after = ntap - g - 2;
+                if (after >= R - 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * NDMAW) : "memory");
+                else if (after == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NDMAW) : "memory");
+                else if (after == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NDMAW) : "memory");
+                else if (after == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMAW) : "memory");
+                else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * NDMAW) : "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();                        // publishes tap g + 1, retires the reads of tap g - 1
+                if (g + R - 1 < ntap) issue_next();
+            }
+        }
+        return;
+    }
+
+    // ================================ consumers (waves 0-3) ================================
+    const int pl = lane & 15, q = lane >> 4;
+    const int co0 = cg * CG;
+    if (tid < CG) {
+        const int co = co0 + tid;
+        float sl = 1.f;
+        if (p.act == SRMI_ACT_RELU) sl = 0.f;
+        else if (p.act == SRMI_ACT_LRELU) sl = p.act_param;
+        else if (p.act == SRMI_ACT_PRELU) sl = p.alpha[p.alpha_pc ? co : 0];
+        par[tid] = p.scale[co];
+        par[64 + tid] = p.shift[co];
+        par[128 + tid] = sl;
+    }
+    int prow[PT], pcol[PT];
+#pragma unroll
+    for (int k = 0; k < PT; ++k) {
+        const int t = wave * PT + k;
+        prow[k] = t / TWT;
+        pcol[k] = (t - prow[k] * TWT) * 16;
+    }
+    int boff[PT][3];
+#pragma unroll
+    for (int k = 0; k < PT; ++k)
+#pragma unroll
+        for (int dx = 0; dx < 3; ++dx) {
+            const int P = prow[k] * ROWP + pcol[k] + pl + dx;
+            boff[k][dx] = P * 128 + ((q ^ c64_key(P)) << 4);
+        }
+    f32x4 acc[PT][NCT];
+#pragma unroll
+    for (int k = 0; k < PT; ++k)
+#pragma unroll
+        for (int t = 0; t < NCT; ++t) acc[k][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool late_relu = p.act == SRMI_ACT_ADD_RELU;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // par[] written before the first barrier
+
+    int s = 0, slot0 = 0;                                          // slot0: ring slot of the stage's first tap
+    for (int it = 0; it < ntl; ++it) {
+        for (int kc = 0; kc < KC; ++kc, ++s) {
+            __builtin_amdgcn_s_barrier();                            // the tile of stage s is in buffer s & 1
+            // B-operand addresses of this stage; the opaque buffer offset keeps hipcc from hoisting the 18 x PT per-step
+            // addresses out of the stage loop (they would live - and spill - across everything)
+            int tb;
+            asm volatile("v_mov_b32 %0, %1" : "=v"(tb) : "s"((s & 1) * IN_BYTES));
+            int bo[PT][3][2];
+#pragma unroll
+            for (int k = 0; k < PT; ++k)
+#pragma unroll
+                for (int dx = 0; dx < 3; ++dx) {
+                    bo[k][dx][0] = boff[k][dx] + tb;
+                    bo[k][dx][1] = (boff[k][dx] ^ 64) + tb;
+                }
+            const bool halfchunk = p.Cin - kc * 64 <= 32;
+            auto ksteps = [&](auto HALFC) {
+                constexpr bool HALF = decltype(HALFC)::value;
+                constexpr int NS = HALF ? 9 : 18;
+                bf16x8 afr[2][NCT], bfr[2][PT];
+                {
+                    const unsigned char* wslot = wring + slot0 * TAP_BYTES + lane * 16;
+#pragma unroll
+                    for (int t = 0; t < NCT; ++t) afr[0][t] = *(const bf16x8*)(wslot + t * 1024);
+#pragma unroll
+                    for (int k = 0; k < PT; ++k) bfr[0][k] = *(const bf16x8*)(lds + bo[k][0][0]);
+                }
+#pragma unroll
+                for (int j = 0; j < NS; ++j) {
+                    const int half = HALF ? 0 : j & 1;
+                    if (HALF || half == 1) __builtin_amdgcn_s_barrier();       // tap + 1 is in the ring
+                    if (j + 1 < NS
+#ifdef SRMI_ABLATE
+                        && !(p.exp & (1 << 24))
+#endif
+                    ) {
+                        const int tapn = HALF ? j + 1 : (j + 1) >> 1, halfn = HALF ? 0 : (j + 1) & 1;
+                        const int dyn = tapn / 3, dxn = tapn - 3 * dyn;
+                        const unsigned char* wslot =
+                            wring + ((slot0 + tapn) % R) * TAP_BYTES + lane * 16 + halfn * (NCT * 1024);
+#pragma unroll
+                        for (int t = 0; t < NCT; ++t) afr[(j + 1) & 1][t] = *(const bf16x8*)(wslot + t * 1024);
+#pragma unroll
+                        for (int k = 0; k < PT; ++k)
+                            bfr[(j + 1) & 1][k] =
+                                *(const bf16x8*)(lds + (bo[k][dxn][halfn] + dyn * (ROWP * 128)));
+                    }
+#ifdef SRMI_ABLATE
+                    if (!(p.exp & (1 << 20)))
+#endif
+                    {
+#pragma unroll
+                    for (int k = 0; k < PT; ++k)
+#pragma unroll
+                        for (int t = 0; t < NCT; ++t)
+                            acc[k][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(afr[j & 1][t], bfr[j & 1][k], acc[k][t], 0, 0, 0);
+                    }
+                    if (j + 1 < NS) sched_interleave<0, NCT + PT, NCT * PT>();
+                }
+            };
+            if (halfchunk) ksteps(std::true_type{});
+            else ksteps(std::false_type{});
+            slot0 = (slot0 + 9) % R;
+        }
+        // ---- epilogue of this tile (as conv_cin_kernel's); the movers are already at work on the next one ----
+        int b = tile0 + it * nslot;
+        const int tx = b % p.tiles_x; b /= p.tiles_x;
+        const int ty = b % p.tiles_y;
+        const int n = b / p.tiles_y;
+        const int y0 = ty * TH, x0 = tx * TW;
+        constexpr int NH = NCT / 2;
+        // every residual line of the tile in flight before the first use (one memory round trip per tile, not one per line)
+        u32x4 rres[PT][NH];
+        if (p.res) {
+#pragma unroll
+            for (int k = 0; k < PT; ++k) {
+                const int oy = min(y0 + prow[k], p.H - 1), ox = min(x0 + pcol[k] + pl, p.W - 1);
+                const size_t pix = ((size_t)n * p.H + oy) * p.W + ox;
+#pragma unroll
+                for (int hi = 0; hi < NH; ++hi) rres[k][hi] = *(const u32x4*)(p.res + pix * p.res_cs + co0 + 32 * hi + 8 * q);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < PT; ++k) {
+            const int oy = y0 + prow[k], ox = x0 + pcol[k] + pl;
+            if (oy < p.H && ox < p.W
+#ifdef SRMI_ABLATE
+                && !(p.exp & (1 << 23))
+#endif
+            ) {
+                const size_t pix = ((size_t)n * p.H + oy) * p.W + ox;
+#pragma unroll
+                for (int hi = 0; hi < NH; ++hi) {
+                    const float* pc = par + 32 * hi + 8 * q;
+                    const f32x4 sc0 = *(const f32x4*)pc, sc1 = *(const f32x4*)(pc + 4);
+                    const f32x4 sh0 = *(const f32x4*)(pc + 64), sh1 = *(const f32x4*)(pc + 68);
+                    const f32x4 sl0 = *(const f32x4*)(pc + 128), sl1 = *(const f32x4*)(pc + 132);
+                    float v[8];
+#pragma unroll
+                    for (int tt = 0; tt < 2; ++tt)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float z = acc[k][2 * hi + tt][e] * (tt ? sc1[e] : sc0[e]) + (tt ? sh1[e] : sh0[e]);
+                            v[4 * tt + e] = z >= 0.f ? z : z * (tt ? sl1[e] : sl0[e]);
+                        }
+                    const int cch = co0 + 32 * hi + 8 * q;
+                    if (p.res) {
+                        const u32x4 r = rres[k][hi];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            v[2 * e] += bf2f((bf16_t)(r[e] & 0xffffu));
+                            v[2 * e + 1] += bf2f((bf16_t)(r[e] >> 16));
+                        }
+                    }
+                    if (late_relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    u32x4 o;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = pack_bf2(v[2 * e], v[2 * e + 1]);
+                    *(u32x4*)(p.y + pix * p.out_cs + p.out_co + cch) = o;
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NCT; ++t) acc[k][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+}
+
 // A-row r (0..15) of channel tile t (0..NCT-1) -> channel within the group
 __host__ __device__ __forceinline__ int cin_row_to_cl(int t, int r) { return 32 * (t >> 1) + 8 * (r >> 2) + 4 * (t & 1) + (r & 3); }
 
@@ -338,6 +668,19 @@ int cin_pack(const srmi_conv_desc& d, const float* w_oihw, void* w_packed, hipSt
     return hip_check(hipGetLastError(), "cin_pack_kernel");
 }
 
+// CUs of the current device (cached per device index)
+static int cin_cus() {
+    static std::atomic<int> cached[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    int c = cached[dev].load(std::memory_order_relaxed);
+    if (!c) {
+        if (hipDeviceGetAttribute(&c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
+        cached[dev].store(c, std::memory_order_relaxed);
+    }
+    return c;
+}
+
 int cin_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     const srmi_conv_desc& d = a.d;
     if (((uintptr_t)a.x | (uintptr_t)a.y | (uintptr_t)a.w | (uintptr_t)a.residual) & 15) {
@@ -352,9 +695,24 @@ int cin_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     p.N = d.N; p.H = d.H; p.W = d.W; p.Cin = d.Cin; p.Cout = d.Cout; p.kchunks = cin_kchunks(d);
     p.in_cs = g.in_cs; p.out_cs = g.out_cs; p.out_co = d.out_coffset; p.res_cs = g.res_cs;
     p.act = d.act; p.act_param = d.act_param; p.alpha_pc = d.alpha_per_channel;
+    p.exp = exp_flags();
     if (d.N == 0 || d.H == 0 || d.W == 0) return SRMI_OK;
     const int nct = cin_nct(d);
     const unsigned gy = (unsigned)(d.Cout / (16 * nct));
+    // many tiles: the persistent, pipelined form (one workgroup per CU; SRMI_DBG bit 17 of the ablation build: off)
+    {
+        const long long tx8 = (d.W + CINP_TW - 1) / CINP_TW, ty8 = (d.H + CINP_TH - 1) / CINP_TH;
+        const long long nt = (long long)d.N * tx8 * ty8;
+        const int cus = cin_cus();
+        if (cus >= 8 && nt >= 4LL * cus && nt <= 0x7fffffffLL && gy <= 65535u && !(dbg_flags() & (1 << 17)) &&
+            (long long)d.H * d.W * g.in_cs * 2 < 0x7fffffffLL) {      // the tile mover's 32-bit buffer offsets
+            p.tiles_x = (int)tx8; p.tiles_y = (int)ty8;
+            const dim3 grid((unsigned)(cus & ~7), gy);
+            if (nct == 4) hipLaunchKernelGGL((conv_cinp_kernel<4>), grid, dim3(512), 0, s, p, (int)nt);
+            else hipLaunchKernelGGL((conv_cinp_kernel<2>), grid, dim3(512), 0, s, p, (int)nt);
+            return hip_check(hipGetLastError(), "conv_cinp_kernel");
+        }
+    }
     int tile = pick_tile3x3(d.N, d.H, d.W);
     static const int th[4] = {6, 8, 4, 8}, tw[4] = {96, 64, 32, 32};
     // 32 output channels per workgroup and several rounds of tiles: 8 x 32 tiles with 4 waves need 77 KB of LDS, so TWO

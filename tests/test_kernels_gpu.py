@@ -221,6 +221,52 @@ def test_cin_bf16_kernel(case):
 
 
 @pytest.mark.parametrize("case", [
+    dict(Cin=64, Cout=32, act=L.ACT_LRELU, act_param=0.2, in_cs=160, out_cs=160, out_co=64),       # RRDB dense conv 1
+    dict(Cin=96, Cout=32, act=L.ACT_LRELU, act_param=0.2, in_cs=160, out_cs=160, out_co=96),       # half last chunk
+    dict(Cin=160, Cout=64, residual=True, res_cs=160),                                             # compress conv + x
+    dict(Cin=128, Cout=128, act=L.ACT_ADD_RELU, residual=True),                                    # two channel groups
+    dict(Cin=32, Cout=64, act=L.ACT_PRELU, alpha_pc=1),                                            # a half chunk only
+])
+def test_cin_bf16_persistent_form_equals_the_per_tile_kernel(case):
+    """With >= 4 tiles of 8 x 32 per CU the K-chunked kernel runs as ONE persistent workgroup per CU whose tiles and
+    weight taps are moved by two dedicated waves (conv_cinp_kernel).  Same arithmetic in the same order: the batch in one
+    call must equal, bit for bit, the images run one call each (few tiles: the launch-per-tile kernel, which
+    test_cin_bf16_kernel pins to the f64 restatement); image 0 is checked against that restatement here as well."""
+    N, H, W = 9, 70, 417                                  # 9 x 14 ragged tiles per image, 1134 in the batch
+    Cin, Cout = case["Cin"], case["Cout"]
+    act, act_param, alpha_pc = case.get("act", L.ACT_NONE), case.get("act_param", 0.0), case.get("alpha_pc", 0)
+    in_cs, out_cs, out_co, res_cs = case.get("in_cs", 0), case.get("out_cs", 0), case.get("out_co", 0), case.get("res_cs", 0)
+    g = _rng(41)
+    x = torch.from_numpy(g.uniform(-1, 1, (N, H, W, in_cs or Cin)).astype(np.float32)).bfloat16().to(DEV)
+    w = torch.from_numpy((g.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32)).bfloat16().float()
+    scale = torch.from_numpy(g.uniform(0.5, 1.5, Cout).astype(np.float32))
+    shift = torch.from_numpy(g.uniform(-0.3, 0.3, Cout).astype(np.float32))
+    alpha = torch.from_numpy(g.uniform(0.05, 0.4, Cout if alpha_pc else 1).astype(np.float32))
+    res = None
+    if case.get("residual"):
+        res = torch.from_numpy(g.uniform(-1, 1, (N, H, W, res_cs or Cout)).astype(np.float32)).bfloat16().to(DEV)
+
+    def run(n, xs, rs):
+        desc = Fn.make_desc(n, H, W, Cin, Cout, 3, in_dtype=L.BF16, out_dtype=L.BF16, res_dtype=L.BF16,
+                            compute=L.COMPUTE_BF16, act=act, act_param=act_param, alpha_per_channel=alpha_pc,
+                            in_cstride=in_cs, out_cstride=out_cs, out_coffset=out_co, res_cstride=res_cs)
+        assert L.kernel_name(desc) == "cin_bf16"
+        y = torch.full((n, H, W, out_cs or Cout), -5.0, dtype=torch.bfloat16, device=DEV)
+        Fn.conv2d_fused(desc, xs, Fn.pack_weights(desc, w.to(DEV)), scale.to(DEV), shift.to(DEV), alpha.to(DEV), rs, out=y)
+        return y
+
+    whole = run(N, x, res)
+    torch.cuda.synchronize()
+    for i in range(N):
+        one = run(1, x[i:i + 1].contiguous(), None if res is None else res[i:i + 1].contiguous())
+        assert torch.equal(whole[i:i + 1], one), f"image {i}"
+    ref = _ref_fused(x[0:1, ..., :Cin].float().cpu().permute(0, 3, 1, 2), w, scale, shift, act, act_param, alpha,
+                     None if res is None else res[0:1, ..., :Cout].float().cpu().permute(0, 3, 1, 2), 1, 1, 1, False)
+    got = whole[0:1, ..., out_co:out_co + Cout].float().cpu().permute(0, 3, 1, 2).double()
+    assert torch.all((got - ref).abs() <= 2.0 ** -8 * (ref.abs() + 1.0))
+
+
+@pytest.mark.parametrize("case", [
     dict(N=2, H=9, W=13, Cin=64, Cout=32, act=L.ACT_RELU),                     # BASELINE config 2's middle layer (9-1-5)
     dict(N=1, H=4, W=4, Cin=32, Cout=16, act=L.ACT_NONE),                      # one pixel tile exactly
     dict(N=3, H=31, W=67, Cin=128, Cout=64, act=L.ACT_LRELU, act_param=0.2),   # many tiles, the 2-tiles-in-flight variant
