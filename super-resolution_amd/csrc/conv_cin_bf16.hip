@@ -14,7 +14,8 @@
 //   * NCT = 4 or 2 channel tiles per workgroup (64 or 32 output channels); more output channels = more
 //     workgroups along grid.y, each re-reading the tile (L2-resident).
 // The chunk hand-off is synchronous (stage -> barrier -> compute): ~60 % of the Cin = 64 kernel's rate, 8-10x the
-// generic f32 kernel's.
+// generic f32 kernel's.  Launches with many tiles run the persistent, wave-specialised form further down
+// (conv_cinp_kernel): same arithmetic, same bits.
 #include <stdlib.h>
 
 #include <atomic>
