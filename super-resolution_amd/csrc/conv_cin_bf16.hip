@@ -700,11 +700,13 @@ int cin_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
     if (d.N == 0 || d.H == 0 || d.W == 0) return SRMI_OK;
     const int nct = cin_nct(d);
     const unsigned gy = (unsigned)(d.Cout / (16 * nct));
-    // many tiles: the persistent, pipelined form (one workgroup per CU; SRMI_DBG bit 17 of the ablation build: off)
+    // many tiles: the persistent, pipelined form (one workgroup per CU; off: SRMI_DBG bit 17 of the ablation build, or a
+    // library built with -DSRMI_NO_CINP, which is what tools/ab_cinp.sh compares against)
     {
         const long long tx8 = (d.W + CINP_TW - 1) / CINP_TW, ty8 = (d.H + CINP_TH - 1) / CINP_TH;
         const long long nt = (long long)d.N * tx8 * ty8;
         const int cus = cin_cus();
+#ifndef SRMI_NO_CINP
         if (cus >= 8 && nt >= 4LL * cus && nt <= 0x7fffffffLL && gy <= 65535u && !(dbg_flags() & (1 << 17)) &&
             (long long)d.H * d.W * g.in_cs * 2 < 0x7fffffffLL) {      // the tile mover's 32-bit buffer offsets
             p.tiles_x = (int)tx8; p.tiles_y = (int)ty8;
@@ -713,6 +715,7 @@ int cin_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
             else hipLaunchKernelGGL((conv_cinp_kernel<2>), grid, dim3(512), 0, s, p, (int)nt);
             return hip_check(hipGetLastError(), "conv_cinp_kernel");
         }
+#endif
     }
     int tile = pick_tile3x3(d.N, d.H, d.W);
     static const int th[4] = {6, 8, 4, 8}, tw[4] = {96, 64, 32, 32};
