@@ -131,9 +131,12 @@ typedef struct srmi_conv_args {
                                  workgroup keeps its tile in LDS from block to block and exchanges the two-pixel halo with
                                  its neighbours through flags in device memory; the 16-block trunk of Generator.forward,
                                  P/srgan_model.py:32-33).  Results are bit-identical to the launch-per-block form, and every
-                                 block's y is still written in full.  Taken only when every workgroup of the chain is
-                                 resident at once (N * ceil(H/12) * ceil(W/48) <= the device's CU count, W > 64, H >= 12,
-                                 >= 2 blocks); otherwise the pairs run one launch each.  What the flag opts into: (1) the
+                                 block's y is still written in full.  Taken only when every workgroup of a launch is
+                                 resident at once (W > 64, H >= 12, >= 2 blocks, and T = ceil(H/12) * ceil(W/48) <= the
+                                 device's CU count): N * T <= CUs is one launch; a bigger batch runs as several chained
+                                 launches of floor(CUs / T) whole images each when those fill the chip well enough to beat
+                                 the launch-per-block form (6 * ceil(N T / CUs) >= 5 * launches), e.g. 32 images of 16 tiles,
+                                 or the five 124 x 976 strips of a 960 x 540 frame; otherwise the pairs run one launch each.  What the flag opts into: (1) the
                                  library allocates 4 KiB of device memory and a 64-byte host-mapped status word per device
                                  at the first such launch (never freed) - make that first call outside a graph capture;
                                  (2) a chained launch on another stream than the previous one first waits on the host for

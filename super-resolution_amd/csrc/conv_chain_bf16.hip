@@ -15,6 +15,7 @@
 // device's CU count and serialises chain launches of different streams.  Every spin is bounded: a workgroup that gives
 // up (another process holds CUs, a lost neighbour) writes a sticky status word in host-visible memory, stops waiting and
 // runs to the end, so the launch always terminates; the next srmi call on that device fails with SRMI_ETIMEOUT.
+#include <algorithm>
 #include <mutex>
 #include <type_traits>
 
@@ -912,6 +913,19 @@ static bool chain_head_ok(const srmi_conv_args& h, const srmi_conv_args& first) 
     return true;
 }
 
+// Every workgroup of a chained launch must be resident at once (one per CU).  A batch with more tiles than CUs runs as
+// several chained launches of k whole images each when that still beats one launch per block: the chain saves ~1/6 of a
+// block's time (20 against 24 us at cfg1), so its fill N tpi / (launches * CUs) times 1.2 has to reach the fill of the
+// launch-per-block form, N tpi / (rounds * CUs).  Returns k, or 0 for "do not chain".
+static int chain_images_per_launch(long long N, long long tpi, long long cus) {
+    if (N <= 0 || tpi <= 0 || tpi > cus || tpi > CHAIN_MAX_TILES) return 0;
+    long long k = cus / tpi;
+    if (k * tpi > CHAIN_MAX_TILES) k = CHAIN_MAX_TILES / tpi;
+    if (k >= N) return (int)N;
+    const long long launches = (N + k - 1) / k, rounds = (N * tpi + cus - 1) / cus;
+    return 6 * rounds >= 5 * launches ? (int)k : 0;           // 1.2 / launches >= 1 / rounds
+}
+
 // Convs of a[0 .. n) that can run as one chain starting at a[0]: L >= 2 ResBlock pairs (a[0], a[1]), (a[2], a[3]), ..., then
 // up to two single-conv tail links (*ntail: conv + residual, then the wide last link; either may be missing): 2 L + ntail,
 // or 0.  `fusable(a1, a2)` is api.hip's test for the fused ResBlock pair.
@@ -926,11 +940,11 @@ int chain_run_length(const srmi_conv_args* a0, int n0, bool (*fusable)(const srm
     {   // cheap rejections first (this runs for every flagged conv of every forward): the shape and the grid
         const srmi_conv_desc& d = a[0].d;
         if (d.W <= 64 || d.H < 12 || d.N <= 0) return 0;
-        const long long nb = (long long)d.N * ((d.W + 47) / 48) * ((d.H + 11) / 12);
+        const long long tpi = (long long)((d.W + 47) / 48) * ((d.H + 11) / 12);     // tiles per image
         std::lock_guard<std::mutex> lk(g_chain_mu);
         ChainDev* cd = chain_dev();
         if (!cd) return 0;
-        if (nb > cd->cus || nb > CHAIN_MAX_TILES) return 0;   // every workgroup must be resident at once (one per CU)
+        if (chain_images_per_launch(d.N, tpi, cd->cus) == 0) return 0;
     }
     int L = 0;
     while (L < CHAIN_MAX_BLOCKS - 2 && 2 * L + 1 < n) {
@@ -1021,18 +1035,42 @@ int chain_launch(const srmi_conv_args* a0, int head, int npairs, const int* kind
             B.xcopy = t.x_copy;
         }
     }
-    const unsigned nb = (unsigned)(p.N * p.tiles_x * p.tiles_y);
     // two persistent grids at once would each hold half the CUs and wait for the other half: a chain launch on another
     // stream than the previous one waits (on the host: rare, and it costs the one-stream case nothing) for that stream
     if (cd->launched && cd->last_stream != s) {
         (void)hipStreamSynchronize(cd->last_stream);      // (a destroyed stream has drained: errors are not ours)
         (void)hipGetLastError();
     }
-    hipLaunchKernelGGL(resblock_chain_kernel, dim3(nb), dim3(512), 0, s, p);
-    int rc = hip_check(hipGetLastError(), "resblock_chain_kernel");
-    if (rc) return rc;
-    cd->launched = true;
-    cd->last_stream = s;
+    // a batch with more tiles than CUs: k whole images per launch (chain_images_per_launch), every per-image pointer advanced
+    const int tpi = p.tiles_x * p.tiles_y;
+    const int kimg = chain_images_per_launch(d.N, tpi, cd->cus);
+    if (kimg <= 0) { set_error("resblock_chain: %d images of %d tiles do not fit %d CUs", d.N, tpi, cd->cus); return SRMI_EINVAL; }
+    const size_t HW = (size_t)d.H * d.W;
+    const ChainParams p0 = p;
+    for (int n0 = 0; n0 < d.N; n0 += kimg) {
+        p = p0;
+        p.N = std::min(kimg, d.N - n0);
+        p.x = p0.x + (size_t)n0 * HW * 64;
+        if (head) {
+            const size_t esz = p0.head.in_bf16 ? 2 : 4;
+            const size_t img = p0.head.in_nchw ? (size_t)p0.head.Cin * HW : HW * p0.head.in_cs;
+            p.head.x = (const char*)p0.head.x + (size_t)n0 * img * esz;
+            p.head.y = p0.head.y + (size_t)n0 * HW * 64;
+        }
+        for (int i = 0; i < p0.nblk; ++i) {
+            const ChainBlk& B0 = p0.blk[i];
+            ChainBlk& B = p.blk[i];
+            const size_t cout = B0.single == 2 ? (size_t)B0.nchunk * 64 : 64;      // the wide link writes H r x W r x Cout / r^2
+            B.y = B0.y + (size_t)n0 * HW * cout;
+            if (B0.res) B.res = B0.res + (size_t)n0 * HW * 64;
+            if (B0.xcopy) B.xcopy = B0.xcopy + (size_t)n0 * HW * 64;
+        }
+        hipLaunchKernelGGL(resblock_chain_kernel, dim3((unsigned)(p.N * tpi)), dim3(512), 0, s, p);
+        int rc = hip_check(hipGetLastError(), "resblock_chain_kernel");
+        if (rc) return rc;
+        cd->launched = true;
+        cd->last_stream = s;
+    }
     return SRMI_OK;
 }
 

@@ -100,7 +100,8 @@ def sr_tiled(fn, lr, tile=(270, 240), halo=8, scale=4, rank=0, world=1, out=None
     for t in tiles:
         groups[(t[5] - t[4], t[7] - t[6])].append(t)          # equal extended shapes share one launch sequence
     for (_eh, _ew), group in groups.items():
-        # max_batch: at most that many tiles per call of fn (1 with strips_for_chain's strips: one chained launch each)
+        # max_batch: at most that many tiles per call of fn (not needed for strips_for_chain's strips: the library runs the
+        # chained front in sub-batches of whole images that fit the CUs and the tail once for the batch)
         step = len(group) if not max_batch else max(1, int(max_batch))
         for g0 in range(0, len(group), step):
             ts = group[g0:g0 + step]

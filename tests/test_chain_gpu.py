@@ -291,10 +291,11 @@ def test_chain_with_head_conv(case):
 def test_chain_refused_shapes_fall_back():
     """More workgroups than CUs, narrow images, a foreign residual: no chain, same results through single launches."""
     lib = L.load()
-    arr, bufs, tmp, keep = _build(8, 96, 200, 3, seed=9)      # 8 * 8 * 5 = 320 workgroups
+    arr, bufs, tmp, keep = _build(8, 144, 576, 3, seed=9)     # 144 workgroups per image: one image per launch would fill 56 % of the chip
     for i in range(0, 6, 2):
         arr[i].flags = L.CONV_FUSE_NEXT | L.CONV_FUSE_CHAIN
     assert lib.srmi_conv2d_chain_length(arr, 6) == 0
+    del arr, bufs, tmp, keep
     arr, bufs, tmp, keep = _build(2, 40, 64, 3, seed=9)       # W <= 64: the small-tile kernel's shapes
     for i in range(0, 6, 2):
         arr[i].flags = L.CONV_FUSE_NEXT | L.CONV_FUSE_CHAIN
@@ -326,6 +327,43 @@ def test_chain_refused_shapes_fall_back():
     _run(arr, 8, L.CONV_FUSE_NEXT)
     for r, b in zip(got, bufs):
         assert torch.equal(r, b)
+
+
+def test_chain_over_sub_batches_of_whole_images():
+    """More tiles than CUs, but whole images fit: the chain runs as several launches of k images each (every per-image
+    pointer advanced) - same bits as one launch per block.  8 x 96 x 200 = 8 x 40 workgroups: 6 + 2 images."""
+    lib = L.load()
+    arr, bufs, tmp, keep = _build(8, 96, 200, 3, seed=9)
+    for i in range(0, 6, 2):
+        arr[i].flags = L.CONV_FUSE_NEXT | L.CONV_FUSE_CHAIN
+    assert lib.srmi_conv2d_chain_length(arr, 6) == 6
+    _run(arr, 6, L.CONV_FUSE_NEXT | L.CONV_FUSE_CHAIN)
+    got = [b.clone() for b in bufs]
+    _run(arr, 6, L.CONV_FUSE_NEXT)
+    assert lib.srmi_chain_status() == 0
+    for r, b in zip(got, bufs):
+        assert torch.equal(r, b)
+    # the whole generator front (head conv, 5 blocks, conv02 + skip, wide up conv with its NCHW f32 copy): 20 images of 16
+    # tiles = 16 + 4 per launch
+    srmi = importlib.import_module("super-resolution_amd.srmi")
+    engine = importlib.import_module("super-resolution_amd.srmi.engine")
+    torch.manual_seed(5)
+    gen = srmi.Generator(img_feat=3, n_feats=64, kernel_size=3, num_block=5, scale=4).to(DEV).eval().set_compute("bf16")
+    x = torch.rand(20, 3, 96, 96, device=DEV)
+    with torch.no_grad():
+        sr1, f1 = gen(x)
+        plan = gen._plans.get(gen, 20, 96, 96, 1)
+        assert any(lbl == "resblock_chain_bf16" and cnt == 13 for (lbl, i0, cnt) in plan.launches), plan.launches
+        engine.set_fuse_chain(False)
+        try:
+            engine.invalidate(gen)
+            sr2, f2 = gen(x)
+        finally:
+            engine.set_fuse_chain(True)
+            engine.invalidate(gen)
+    torch.cuda.synchronize()
+    assert torch.equal(sr1, sr2) and torch.equal(f1, f2)
+    assert lib.srmi_chain_status() == 0
 
 
 def test_generator_chain_switch():

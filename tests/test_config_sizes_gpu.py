@@ -88,9 +88,10 @@ def test_cfg5_equal_extended_tiles_match_generator_on_crops():
 
 
 def test_cfg5_chain_strips_match_launch_per_block_on_crops():
-    """cfg5 as bench.py times it on a GPU whose CUs hold one strip's tiles: horizontal strips (tiling.strips_for_chain), one
-    call per strip, each call's front ONE chained launch - against `Generator` on the same crops with the chain switched
-    off (one launch per ResBlock): bit-identical."""
+    """cfg5 as bench.py times it on a GPU whose CUs hold one strip's tiles: horizontal strips (tiling.strips_for_chain), all
+    strips of the frame as ONE batch (the library runs the chained front strip by strip and the fused tail once), and one call
+    per strip - both against `Generator` on the same crops with the chain switched off (one launch per ResBlock):
+    bit-identical."""
     from importlib import import_module
     engine = import_module("super-resolution_amd.srmi.engine")
     cus = torch.cuda.get_device_properties(DEV).multi_processor_count
@@ -108,6 +109,10 @@ def test_cfg5_chain_strips_match_launch_per_block_on_crops():
         t = plan[0]
         p0 = gen._plans.get(gen, 1, t[5] - t[4], t[7] - t[6], 1)
         assert any(lbl == "resblock_chain_bf16" for (lbl, i0, cnt) in p0.launches), p0.launches
+        batched, n = tiling.sr_tiled(gen, x, halo=8, grid=(ny, 1))
+        pb = gen._plans.get(gen, ny, t[5] - t[4], t[7] - t[6], 1)
+        assert any(lbl == "resblock_chain_bf16" for (lbl, i0, cnt) in pb.launches), pb.launches
+        assert torch.equal(batched, stitched)
         engine.set_fuse_chain(False)
         try:
             engine.invalidate(gen)

@@ -99,19 +99,24 @@ def cfg2(steps=10, warmup=3, compute="bf16", per_layer=True):
                 steps, warmup, compute, per_layer=per_layer)]
 
 
-def cfg5_tiling(dev="cuda:0", H=540, W=960, halo=8):
+def cfg5_tiling(dev="cuda:0", H=540, W=960, halo=8, per_strip=False):
     """How a 960x540 frame is cut: horizontal strips that each fit the GPU as ONE chained launch of the generator's front
-    (srmi.tiling.strips_for_chain: 5 strips of 121 x 960 on 256 CUs, one call per strip), else 2 x 4 tiles as one batch."""
+    (srmi.tiling.strips_for_chain: 5 strips of 121 x 960 on 256 CUs), all strips of a frame as one batch: the library runs
+    the front strip by strip and the fused tail once for the batch (per_strip: one call per strip, the form before the
+    chain took sub-batches); else 2 x 4 tiles as one batch."""
     from srmi import engine
     from srmi.tiling import strips_for_chain
     cus = torch.cuda.get_device_properties(dev).multi_processor_count
     ny = strips_for_chain(H, W, halo, cus) if engine._FUSE_CHAIN else None
     if ny is not None and ny <= 8:
-        return dict(grid=(ny, 1), max_batch=1), f"{ny} strips of equal extended shape (one chained launch of the front each)"
+        if per_strip:
+            return dict(grid=(ny, 1), max_batch=1), f"{ny} strips of equal extended shape (one chained launch of the front each)"
+        return dict(grid=(ny, 1)), (f"{ny} strips of equal extended shape as one batch (one chained launch of the front per strip, "
+                                    "one fused-tail launch for all)")
     return dict(grid=(2, 4)), "2 x 4 tiles of equal extended shape 278x252, one batch of eight"
 
 
-def cfg5(steps=10, warmup=3, compute="bf16", gen=None):
+def cfg5(steps=10, warmup=3, compute="bf16", gen=None, per_strip=False):
     """BASELINE config 5 on ONE GPU: one 960x540 frame -> 3840x2160 with the 8 px halo (tiling: cfg5_tiling)."""
     from srmi.srgan_model import Generator
     from srmi.tiling import sr_tiled
@@ -121,7 +126,7 @@ def cfg5(steps=10, warmup=3, compute="bf16", gen=None):
         gen.load_state_dict(synthetic_state(gen, 0))
         gen = gen.to("cuda:0").eval().set_compute(compute)
     frame = (torch.rand(1, 3, 540, 960, generator=torch.Generator().manual_seed(0)) * 2 - 1).to("cuda:0")
-    kw, how = cfg5_tiling()
+    kw, how = cfg5_tiling(per_strip=per_strip)
     with torch.no_grad():
         for _ in range(warmup):
             sr_tiled(gen, frame, halo=8, **kw)
