@@ -5,7 +5,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "super-resolution_amd")]
 import torch
 import bench
-for n in (2, 4, 8, 16):
+for n in (8, 16, 24, 32, 48):
     bench.BATCH = n
     gen, x, _, _ = bench.build_generator(torch.device("cuda:0"), "bf16")
     with torch.no_grad():
