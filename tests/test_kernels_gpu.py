@@ -229,10 +229,42 @@ def test_cin_bf16_kernel(case):
 ])
 def test_cin_bf16_persistent_form_equals_the_per_tile_kernel(case):
     """With >= 4 tiles of 8 x 32 per CU the K-chunked kernel runs as ONE persistent workgroup per CU whose tiles and
-    weight taps are moved by two dedicated waves (conv_cinp_kernel).  Same arithmetic in the same order: the batch in one
+    weight taps are moved by dedicated waves (conv_cinp_kernel).  Same arithmetic in the same order: the batch in one
     call must equal, bit for bit, the images run one call each (few tiles: the launch-per-tile kernel, which
     test_cin_bf16_kernel pins to the f64 restatement); image 0 is checked against that restatement here as well."""
-    N, H, W = 9, 70, 417                                  # 9 x 14 ragged tiles per image, 1134 in the batch
+    _cinp_check(9, 70, 417, case)                         # 9 x 14 ragged tiles per image, 1134 in the batch
+
+
+def _cinp_fuzz_cases(n, seed):
+    g = _rng(seed)
+    out = []
+    for _ in range(n):
+        H, W = int(g.integers(17, 130)), int(g.integers(65, 520))
+        tpi = -(-H // 8) * -(-W // 32)
+        N = max(2, -(-1024 // tpi) + int(g.integers(0, 3)))          # >= 1024 tiles in the batch, < 1024 per image
+        Cin, Cout = int(g.choice([32, 64, 96, 128, 160, 192])), int(g.choice([32, 64, 96]))
+        if Cin == 64 and Cout == 64:
+            Cout = 96                                                # (64 -> 64 is the Cin = 64 kernel's)
+        c = dict(N=N, H=H, W=W, Cin=Cin, Cout=Cout,
+                 act=int(g.choice([L.ACT_NONE, L.ACT_RELU, L.ACT_LRELU, L.ACT_PRELU, L.ACT_ADD_RELU])), act_param=0.2,
+                 alpha_pc=int(g.integers(0, 2)), residual=bool(g.integers(0, 2)))
+        if g.integers(0, 2):
+            c.update(in_cs=Cin + 8 * int(g.integers(0, 9)), out_cs=Cout + 8 * int(g.integers(1, 9)))
+            c["out_co"] = 8 * int(g.integers(0, (c["out_cs"] - Cout) // 8 + 1))
+            if c["residual"]:
+                c["res_cs"] = Cout + 8 * int(g.integers(0, 5))
+        out.append(c)
+    return out
+
+
+@pytest.mark.parametrize("case", _cinp_fuzz_cases(8, seed=23))
+def test_cin_bf16_persistent_form_fuzz(case):
+    """Seeded shapes, channel counts, slices and epilogues for the persistent form: batch call == per-image calls, bit for bit."""
+    assert case["N"] * -(-case["H"] // 8) * -(-case["W"] // 32) >= 1024 > -(-case["H"] // 8) * -(-case["W"] // 32)
+    _cinp_check(case["N"], case["H"], case["W"], case, check_ref=False)
+
+
+def _cinp_check(N, H, W, case, check_ref=True):
     Cin, Cout = case["Cin"], case["Cout"]
     act, act_param, alpha_pc = case.get("act", L.ACT_NONE), case.get("act_param", 0.0), case.get("alpha_pc", 0)
     in_cs, out_cs, out_co, res_cs = case.get("in_cs", 0), case.get("out_cs", 0), case.get("out_co", 0), case.get("res_cs", 0)
@@ -260,6 +292,8 @@ def test_cin_bf16_persistent_form_equals_the_per_tile_kernel(case):
     for i in range(N):
         one = run(1, x[i:i + 1].contiguous(), None if res is None else res[i:i + 1].contiguous())
         assert torch.equal(whole[i:i + 1], one), f"image {i}"
+    if not check_ref:
+        return
     ref = _ref_fused(x[0:1, ..., :Cin].float().cpu().permute(0, 3, 1, 2), w, scale, shift, act, act_param, alpha,
                      None if res is None else res[0:1, ..., :Cout].float().cpu().permute(0, 3, 1, 2), 1, 1, 1, False)
     got = whole[0:1, ..., out_co:out_co + Cout].float().cpu().permute(0, 3, 1, 2).double()
