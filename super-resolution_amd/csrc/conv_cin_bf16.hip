@@ -295,12 +295,14 @@ __global__ __launch_bounds__(NW * 64, WGPC) void conv_cin_kernel(CinParams p) {
 // the next: all workgroups of a round do so in step, so HBM idles while the matrix cores run and the other way round
 // (rocprofv3: 2.4-3.1 TB/s of traffic AND 0.20-0.35 MFMA-pipe busy, profiles/r3_cfg4_layers.json).  Here one workgroup
 // per CU walks through its tiles with the work split over SPECIALISED waves:
-//   waves 0-3  (consumers) : LDS reads, MFMAs, the epilogue and its stores - no vector-memory wait anywhere;
-//   wave 4     (tile mover): LDS-DMA of the NEXT stage's halo tile (stage = one 64-channel chunk of one 8 x 32 tile,
-//                            50 pieces of 1 KiB, swizzle applied on the source side, borders / padded channels read from
-//                            a zero line) into the other tile buffer while the consumers work; vmcnt(0) once per stage;
-//   wave 5     (tap mover) : the 4-slot weight ring of the kernel above (tap g + 3 issued when tap g - 1 is retired, a
-//                            counted vmcnt per tap), as its own in-order stream.
+//   waves 0-7   (consumers)   : LDS reads, MFMAs, the epilogue and its stores - no vector-memory wait in the K loops;
+//   waves 8-9   (tile movers) : the NEXT stage's halo tile (stage = one 64-channel chunk of one 8 x 32 tile: 10 rows of
+//                               5 pieces of 1 KiB) by `buffer_load_dwordx4 ... lds` into the other tile buffer, five rows
+//                               each, while the consumers work; the swizzle is applied on the source side, border pixels
+//                               and the padded channels of a half chunk carry an offset beyond the buffer resource and
+//                               read zeros; vmcnt(0) once per stage;
+//   waves 10-11 (tap movers)  : the weight ring of the kernel above, 8 or 6 slots deep, half a tap each (tap g + R - 1
+//                               issued when tap g - 1 is retired, a counted vmcnt per tap), as their own in-order streams.
 // Three streams because vmcnt retires in order per wave: taps (needed three steps later) queued behind a tile (needed a
 // stage later, a full HBM latency) would wait for it.  Every wave executes the same barriers: one per stage (the tile
 // of the stage has landed / the previous stage's buffer is free) and one per tap (as above).  All loops are counted:
@@ -309,9 +311,10 @@ constexpr int CINP_TH = 8, CINP_TW = 32, CINP_ROWP = 40;
 constexpr int CINP_IN_BYTES = (CINP_TH + 2) * CINP_ROWP * 128;      // 51200 = 10 rows x 5 DMA pieces of 1 KiB
 constexpr int cinp_ring(int nct) { return nct == 2 ? 8 : 6; }      // weight ring slots (LDS: 136 KB / 152 KB per workgroup)
 
-template <int NCT>
-__global__ __launch_bounds__(512, 1) void conv_cinp_kernel(CinParams p, int ntiles) {
-    constexpr int TH = CINP_TH, TW = CINP_TW, TWT = 2, ROWP = CINP_ROWP, PT = 4;
+// NCW consumer waves (4: one per SIMD, 4 pixel tiles each; 8: two per SIMD, 2 pixel tiles each), then 2 tile movers, 2 tap movers
+template <int NCT, int NCW>
+__global__ __launch_bounds__((NCW + 4) * 64, 1) void conv_cinp_kernel(CinParams p, int ntiles) {
+    constexpr int TH = CINP_TH, TW = CINP_TW, TWT = 2, ROWP = CINP_ROWP, PT = 16 / NCW;
     constexpr int IN_BYTES = CINP_IN_BYTES;
     constexpr int TAP_BYTES = 2 * NCT * 1024;
     constexpr int NDMAW = TAP_BYTES / 2048;            // LDS-DMA instructions per tap and tap mover (two waves move a tap)
@@ -337,9 +340,9 @@ __global__ __launch_bounds__(512, 1) void conv_cinp_kernel(CinParams p, int ntil
     const int cg = blockIdx.y;
     const int tile0 = xcd * per_xcd + slot;
 
-    if (wave == 4 || wave == 5) {
+    if (wave == NCW || wave == NCW + 1) {
         // ================================ tile movers (rows 0-4 / 5-9 of the halo tile) ================================
-        const int r0 = (wave - 4) * 5;
+        const int r0 = (wave - NCW) * 5;
         // buffer loads with the LDS as destination: lanes outside the image (or past the chunk's real channels) carry an
         // offset beyond the resource and read zeros - the padding of the conv and of a half chunk
         const int pos = lane & 7, sub = lane >> 3;
@@ -398,11 +401,11 @@ __global__ __launch_bounds__(512, 1) void conv_cinp_kernel(CinParams p, int ntil
         return;
     }
 
-    if (wave >= 6) {
+    if (wave >= NCW + 2) {
         // ================================ tap movers (each one half of every tap) ================================
         const int ntap = nstage * 9;
-        const unsigned char* wbase = (const unsigned char*)p.w + (size_t)cg * KC * 9 * TAP_BYTES + (wave - 6) * (TAP_BYTES / 2) + lane * 16;
-        const unsigned wring_lds = (unsigned)(uintptr_t)(lptr_t)wring + (unsigned)((wave - 6) * (TAP_BYTES / 2));
+        const unsigned char* wbase = (const unsigned char*)p.w + (size_t)cg * KC * 9 * TAP_BYTES + (wave - NCW - 2) * (TAP_BYTES / 2) + lane * 16;
+        const unsigned wring_lds = (unsigned)(uintptr_t)(lptr_t)wring + (unsigned)((wave - NCW - 2) * (TAP_BYTES / 2));
         int islot = 0, is = 0, itap = 0;                             // ring slot / stage / tap of the next tap to issue
         auto issue_next = [&]() {
 #ifdef SRMI_ABLATE
@@ -449,7 +452,7 @@ __global__ __launch_bounds__(512, 1) void conv_cinp_kernel(CinParams p, int ntil
         return;
     }
 
-    // ================================ consumers (waves 0-3) ================================
+    // ================================ consumers (waves 0 .. NCW-1) ================================
     const int pl = lane & 15, q = lane >> 4;
     const int co0 = cg * CG;
     if (tid < CG) {
@@ -711,8 +714,16 @@ int cin_launch(const srmi_conv_args& a, const ConvGeom& g, hipStream_t s) {
             (long long)d.H * d.W * g.in_cs * 2 < 0x7fffffffLL) {      // the tile mover's 32-bit buffer offsets
             p.tiles_x = (int)tx8; p.tiles_y = (int)ty8;
             const dim3 grid((unsigned)(cus & ~7), gy);
-            if (nct == 4) hipLaunchKernelGGL((conv_cinp_kernel<4>), grid, dim3(512), 0, s, p, (int)nt);
-            else hipLaunchKernelGGL((conv_cinp_kernel<2>), grid, dim3(512), 0, s, p, (int)nt);
+            // eight consumer waves (two per SIMD, 2 pixel tiles each: one fills the other's barrier / LDS-latency bubbles) beat four
+            // (4 pixel tiles each) on every layer measured: 64->32 36.1 -> 31.9 us, 128->32 56.4 -> 51.1, 160->64 105 -> 100.7,
+            // 128->64 81.5 -> 75.5 at 8 x 256 x 256 (A/B build: -DSRMI_CINP_NCW4)
+#ifdef SRMI_CINP_NCW4
+            if (nct == 4) hipLaunchKernelGGL((conv_cinp_kernel<4, 4>), grid, dim3(512), 0, s, p, (int)nt);
+            else hipLaunchKernelGGL((conv_cinp_kernel<2, 4>), grid, dim3(512), 0, s, p, (int)nt);
+#else
+            if (nct == 4) hipLaunchKernelGGL((conv_cinp_kernel<4, 8>), grid, dim3(768), 0, s, p, (int)nt);
+            else hipLaunchKernelGGL((conv_cinp_kernel<2, 8>), grid, dim3(768), 0, s, p, (int)nt);
+#endif
             return hip_check(hipGetLastError(), "conv_cinp_kernel");
         }
 #endif
