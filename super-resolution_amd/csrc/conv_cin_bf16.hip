@@ -301,15 +301,16 @@ __global__ __launch_bounds__(NW * 64, WGPC) void conv_cin_kernel(CinParams p) {
 //                               each, while the consumers work; the swizzle is applied on the source side, border pixels
 //                               and the padded channels of a half chunk carry an offset beyond the buffer resource and
 //                               read zeros; vmcnt(0) once per stage;
-//   waves 10-11 (tap movers)  : the weight ring of the kernel above, 8 or 6 slots deep, half a tap each (tap g + R - 1
-//                               issued when tap g - 1 is retired, a counted vmcnt per tap), as their own in-order streams.
+//   waves 10-11 (tap movers)  : the weight ring, in UNITS of three taps (one tap row, 12 / 24 KiB), 3 or 2 slots, half a
+//                               unit each (unit g + RU - 1 issued when unit g - 1 is retired, a counted vmcnt per unit),
+//                               as their own in-order streams.
 // Three streams because vmcnt retires in order per wave: taps (needed three steps later) queued behind a tile (needed a
-// stage later, a full HBM latency) would wait for it.  Every wave executes the same barriers: one per stage (the tile
-// of the stage has landed / the previous stage's buffer is free) and one per tap (as above).  All loops are counted:
+// stage later, a full HBM latency) would wait for it.  Every wave executes the same barriers: three per stage, one in front
+// of every unit (the first one also says: the tile of the stage has landed, the previous stage's buffer is free).  All loops are counted:
 // no wave waits on another workgroup.  Arithmetic and order of summation are those of conv_cin_kernel: same bits.
 constexpr int CINP_TH = 8, CINP_TW = 32, CINP_ROWP = 40;
 constexpr int CINP_IN_BYTES = (CINP_TH + 2) * CINP_ROWP * 128;      // 51200 = 10 rows x 5 DMA pieces of 1 KiB
-constexpr int cinp_ring(int nct) { return nct == 2 ? 8 : 6; }      // weight ring slots (LDS: 136 KB / 152 KB per workgroup)
+constexpr int cinp_ring(int nct) { return nct == 2 ? 3 : 2; }      // weight ring slots of three taps each (LDS: 140 KB / 152 KB per workgroup)
 
 // NCW consumer waves (4: one per SIMD, 4 pixel tiles each; 8: two per SIMD, 2 pixel tiles each), then 2 tile movers, 2 tap movers
 template <int NCT, int NCW>
@@ -317,12 +318,15 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv_cinp_kernel(CinParams 
     constexpr int TH = CINP_TH, TW = CINP_TW, TWT = 2, ROWP = CINP_ROWP, PT = 16 / NCW;
     constexpr int IN_BYTES = CINP_IN_BYTES;
     constexpr int TAP_BYTES = 2 * NCT * 1024;
-    constexpr int NDMAW = TAP_BYTES / 2048;            // LDS-DMA instructions per tap and tap mover (two waves move a tap)
-    constexpr int R = cinp_ring(NCT);
+    // the weight ring moves in UNITS of three taps (one tap row): one barrier per unit instead of one per tap - at 8-16 MFMAs
+    // per wave and tap a barrier per tap re-aligned the two waves of a SIMD every 128-256 cycles
+    constexpr int UNIT_BYTES = 3 * TAP_BYTES;
+    constexpr int NDU = UNIT_BYTES / 2048;             // LDS-DMA instructions per unit and tap mover (two waves move a unit)
+    constexpr int RU = cinp_ring(NCT);                 // ring slots (units)
     constexpr int CG = NCT * 16;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * IN_BYTES + R * TAP_BYTES + 3 * 64 * 4];
+    __shared__ __attribute__((aligned(16))) unsigned char lds[2 * IN_BYTES + RU * UNIT_BYTES + 3 * 64 * 4];
     unsigned char* const wring = lds + 2 * IN_BYTES;
-    float* const par = (float*)(lds + 2 * IN_BYTES + R * TAP_BYTES);
+    float* const par = (float*)(lds + 2 * IN_BYTES + RU * UNIT_BYTES);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -371,6 +375,9 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv_cinp_kernel(CinParams 
             }
         };
         auto issue_row = [&](int r) {
+#ifdef SRMI_CINP_EXP_FEWER_ROWS      // experiment build (wrong results): 2 of every 5 tile rows are not loaded
+            if (r % 5 >= 3) return;
+#endif
 #ifdef SRMI_ABLATE
             if (p.exp & (1 << 21)) return;
 #endif
@@ -391,31 +398,29 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv_cinp_kernel(CinParams 
             const bool more = s + 1 < nstage;
             // the whole next tile is requested within the first three tap steps (a stage of lead: what is in flight per CU
             // over the memory latency is the bandwidth the pipeline can draw), in slices so as not to be late at a barrier
-            if (more) { setup(s + 1); issue_row(r0); issue_row(r0 + 1); }
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                __builtin_amdgcn_s_barrier();
-                if (more && t < 3) issue_row(r0 + 2 + t);
-            }
+            if (more) { setup(s + 1); issue_row(r0); issue_row(r0 + 1); issue_row(r0 + 2); }
+            __builtin_amdgcn_s_barrier();                            // unit barriers 1 and 2 of the stage
+            if (more) { issue_row(r0 + 3); issue_row(r0 + 4); }
+            __builtin_amdgcn_s_barrier();
         }
         return;
     }
 
     if (wave >= NCW + 2) {
-        // ================================ tap movers (each one half of every tap) ================================
-        const int ntap = nstage * 9;
-        const unsigned char* wbase = (const unsigned char*)p.w + (size_t)cg * KC * 9 * TAP_BYTES + (wave - NCW - 2) * (TAP_BYTES / 2) + lane * 16;
-        const unsigned wring_lds = (unsigned)(uintptr_t)(lptr_t)wring + (unsigned)((wave - NCW - 2) * (TAP_BYTES / 2));
-        int islot = 0, is = 0, itap = 0;                             // ring slot / stage / tap of the next tap to issue
+        // ================================ tap movers (each one half of every unit) ================================
+        const int nunit = nstage * 3;
+        const unsigned char* wbase = (const unsigned char*)p.w + (size_t)cg * KC * 9 * TAP_BYTES + (wave - NCW - 2) * (UNIT_BYTES / 2) + lane * 16;
+        const unsigned wring_lds = (unsigned)(uintptr_t)(lptr_t)wring + (unsigned)((wave - NCW - 2) * (UNIT_BYTES / 2));
+        int islot = 0, is = 0, iu = 0;                               // ring slot / stage / unit-in-stage of the next unit to issue
         auto issue_next = [&]() {
 #ifdef SRMI_ABLATE
             if (p.exp & (1 << 22)) return;
 #endif
             const int kc = is % KC;
-            const unsigned char* src = wbase + (size_t)(kc * 9 + itap) * TAP_BYTES;
-            const unsigned dst = __builtin_amdgcn_readfirstlane(wring_lds + (unsigned)(islot * TAP_BYTES));
+            const unsigned char* src = wbase + (size_t)(kc * 9 + 3 * iu) * TAP_BYTES;      // taps 3 iu .. 3 iu + 2: contiguous
+            const unsigned dst = __builtin_amdgcn_readfirstlane(wring_lds + (unsigned)(islot * UNIT_BYTES));
 #pragma unroll
-            for (int i = 0; i < NDMAW; ++i) {
+            for (int i = 0; i < NDU; ++i) {
                 unsigned keep;
                 asm volatile(
                     "s_mov_b32 %0, m0\n\t"
@@ -427,27 +432,17 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv_cinp_kernel(CinParams 
                     : "v"(src + i * 1024), "s"(dst + (unsigned)(i * 1024))
                     : "memory");
             }
-            if (++islot == R) islot = 0;
-            if (++itap == 9) { itap = 0; ++is; }
+            if (++islot == RU) islot = 0;
+            if (++iu == 3) { iu = 0; ++is; }
         };
-        // taps 0 .. R-2 up front (ntap >= 9 > R - 2); tap g + R - 1 follows when tap g - 1 is retired
-        for (int i = 0; i < R - 1; ++i) issue_next();
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 2) * NDMAW) : "memory");     // tap 0 landed
-        int g = 0;
-        for (int s = 0; s < nstage; ++s) {
-            __builtin_amdgcn_s_barrier();
-            for (int t = 0; t < 9; ++t, ++g) {
-                // tap g + 1 landed; the taps issued after it (at most R - 3, fewer at the end of the stream) may stay in flight
-                const int after = ntap - g - 2;
-                if (after >= R - 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((R - 3) * NDMAW) : "memory");
-                else if (after == 4) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * NDMAW) : "memory");
-                else if (after == 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NDMAW) : "memory");
-                else if (after == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NDMAW) : "memory");
-                else if (after == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * NDMAW) : "memory");
-                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();                        // publishes tap g + 1, retires the reads of tap g - 1
-                if (g + R - 1 < ntap) issue_next();
-            }
+        // units 0 .. RU-2 up front (nunit >= 3 > RU - 2); unit g + RU - 1 follows when unit g - 1 is retired
+        for (int i = 0; i < RU - 1; ++i) issue_next();
+        for (int g = 0; g < nunit; ++g) {
+            // unit g landed; the units issued after it (RU - 2, none at the end of the stream) may stay in flight
+            if (RU > 2 && g + RU - 2 < nunit) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((RU - 2) * NDU) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                            // publishes unit g; the consumers' reads of unit g - 1 are complete
+            if (g + RU - 1 < nunit) issue_next();
         }
         return;
     }
@@ -488,7 +483,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv_cinp_kernel(CinParams 
     const bool late_relu = p.act == SRMI_ACT_ADD_RELU;
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");       // par[] written before the first barrier
 
-    int s = 0, slot0 = 0;                                          // slot0: ring slot of the stage's first tap
+    int s = 0, slot0 = 0;                                          // slot0: ring slot of the stage's first unit
     for (int it = 0; it < ntl; ++it) {
         for (int kc = 0; kc < KC; ++kc, ++s) {
             __builtin_amdgcn_s_barrier();                            // the tile of stage s is in buffer s & 1
@@ -510,7 +505,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv_cinp_kernel(CinParams 
                 constexpr int NS = HALF ? 9 : 18;
                 bf16x8 afr[2][NCT], bfr[2][PT];
                 {
-                    const unsigned char* wslot = wring + slot0 * TAP_BYTES + lane * 16;
+                    const unsigned char* wslot = wring + slot0 * UNIT_BYTES + lane * 16;
 #pragma unroll
                     for (int t = 0; t < NCT; ++t) afr[0][t] = *(const bf16x8*)(wslot + t * 1024);
 #pragma unroll
@@ -518,8 +513,13 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv_cinp_kernel(CinParams 
                 }
 #pragma unroll
                 for (int j = 0; j < NS; ++j) {
-                    const int half = HALF ? 0 : j & 1;
-                    if (HALF || half == 1) __builtin_amdgcn_s_barrier();       // tap + 1 is in the ring
+                    {   // the step after this one opens a new unit (tap 3 or 6): every read of the old one complete, then the barrier
+                        constexpr int SPU = HALF ? 3 : 6;                      // steps per unit
+                        if (j + 1 < NS && (j + 1) % SPU == 0) {
+                            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                            __builtin_amdgcn_s_barrier();
+                        }
+                    }
                     if (j + 1 < NS
 #ifdef SRMI_ABLATE
                         && !(p.exp & (1 << 24))
@@ -528,7 +528,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv_cinp_kernel(CinParams 
                         const int tapn = HALF ? j + 1 : (j + 1) >> 1, halfn = HALF ? 0 : (j + 1) & 1;
                         const int dyn = tapn / 3, dxn = tapn - 3 * dyn;
                         const unsigned char* wslot =
-                            wring + ((slot0 + tapn) % R) * TAP_BYTES + lane * 16 + halfn * (NCT * 1024);
+                            wring + ((slot0 + tapn / 3) % RU) * UNIT_BYTES + (tapn % 3) * TAP_BYTES + lane * 16 + halfn * (NCT * 1024);
 #pragma unroll
                         for (int t = 0; t < NCT; ++t) afr[(j + 1) & 1][t] = *(const bf16x8*)(wslot + t * 1024);
 #pragma unroll
@@ -551,7 +551,7 @@ __global__ __launch_bounds__((NCW + 4) * 64, 1) void conv_cinp_kernel(CinParams 
             };
             if (halfchunk) ksteps(std::true_type{});
             else ksteps(std::false_type{});
-            slot0 = (slot0 + 9) % R;
+            slot0 = (slot0 + 3) % RU;
         }
         // ---- epilogue of this tile (as conv_cin_kernel's); the movers are already at work on the next one ----
         int b = tile0 + it * nslot;
