@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the ablation build's run-time switches sit inside the persistent kernel's loops and cost it ~25 % (cfg4 8.8 ms
+# against 6.9 for the product build): read these numbers against each other only; product-build A/Bs: tools/ab_cinp.sh.
 # Ablations of the persistent K-chunked conv (ablation build, SRMI_EXP bits 20-22; SRMI_DBG bit 17 = launch-per-tile kernel)
 # on the four layers of an RRDB dense block at cfg4's size.  Through gpurun.
 R=${GRAFT_REPO_ROOT:-/root/repo}

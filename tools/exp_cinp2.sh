@@ -1,4 +1,6 @@
 #!/bin/bash
+# NOTE: the ablation build's run-time switches sit inside the persistent kernel's loops and cost it ~25 % (cfg4 8.8 ms
+# against 6.9 for the product build): read these numbers against each other only; product-build A/Bs: tools/ab_cinp.sh.
 R=${GRAFT_REPO_ROOT:-/root/repo}
 export SRMI_LIB=$R/super-resolution_amd/srmi/lib/libsrmi_ablate.so
 run() {
