@@ -169,8 +169,9 @@ int srmi_version(void);
 /* message for the calling thread's most recent failure ("" if none). */
 const char* srmi_last_error(void);
 
-/* name of the kernel that RUNS the forward conv of `d`: bf16 path "c64_bf16", "cin_bf16", "c64_thin_bf16", "k9c3_bf16" (9x9 / pad 4 or
- * 3x3 / pad 1 conv of a <= 3-channel image),
+/* name of the kernel that RUNS the forward conv of `d`: bf16 path "c64_bf16", "cin_bf16" (K-chunked 3x3; launches with at least
+ * four 8 x 32 tiles per CU run its persistent, wave-specialised form conv_cinp_kernel: same packed weights, same bits),
+ * "c64_thin_bf16", "k9c3_bf16" (9x9 / pad 4 or 3x3 / pad 1 conv of a <= 3-channel image),
  * "k9c1_bf16", "pw_bf16", "c1out_bf16"; f32 path "b3h_f32" (split-bf16, 3x3 / 64 input channels, halo tile in LDS),
  * "b3_f32" (split-bf16, general), "f32t" (exact f32 MFMA, LDS-tiled), "thin_f32" (<= 4 channels on one side, stride 1,
  * <= 9 taps, shift-only epilogue plus - on the <= 4 -> 64 side - a slope activation: fmaf chains on the vector ALU, HBM-bound), "generic_f32" (exact f32 MFMA, no LDS: NCHW or
