@@ -264,6 +264,45 @@ def test_cin_bf16_persistent_form_fuzz(case):
     _cinp_check(case["N"], case["H"], case["W"], case, check_ref=False)
 
 
+def test_cin_bf16_persistent_form_soak_two_streams():
+    """The persistent form's hand-offs (tile buffers, weight ring: barriers and counted vmcnt only, no state outside the
+    workgroup) under repetition and under contention: 40 launches back to back, the second half of them while a second
+    stream runs the same kernel on other tensors (the two grids then share the CUs workgroup by workgroup) - every
+    output equal to the first, bit for bit."""
+    N, H, W, Cin, Cout = 8, 128, 256, 160, 64
+    g = _rng(5)
+    desc = Fn.make_desc(N, H, W, Cin, Cout, 3, in_dtype=L.BF16, out_dtype=L.BF16, res_dtype=L.BF16, compute=L.COMPUTE_BF16,
+                        act=L.ACT_LRELU, act_param=0.2)
+    assert L.kernel_name(desc) == "cin_bf16"
+
+    def make(seed):
+        gg = _rng(seed)
+        x = torch.from_numpy(gg.uniform(-1, 1, (N, H, W, Cin)).astype(np.float32)).bfloat16().to(DEV)
+        w = torch.from_numpy((gg.standard_normal((Cout, Cin, 3, 3)) / np.sqrt(Cin * 9)).astype(np.float32))
+        return x, Fn.pack_weights(desc, w.to(DEV))
+
+    (xa, wa), (xb, wb) = make(1), make(2)
+    scale = torch.from_numpy(g.uniform(0.5, 1.5, Cout).astype(np.float32)).to(DEV)
+    shift = torch.from_numpy(g.uniform(-0.3, 0.3, Cout).astype(np.float32)).to(DEV)
+    alpha = torch.zeros(1, device=DEV)
+    outs = [torch.empty((N, H, W, Cout), dtype=torch.bfloat16, device=DEV) for _ in range(40)]
+    yb = torch.empty((N, H, W, Cout), dtype=torch.bfloat16, device=DEV)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for it in range(40):
+        if it >= 20:
+            with torch.cuda.stream(side):
+                Fn.conv2d_fused(desc, xb, wb, scale, shift, alpha, None, out=yb)
+        Fn.conv2d_fused(desc, xa, wa, scale, shift, alpha, None, out=outs[it])
+    torch.cuda.synchronize()
+    bad = [it for it in range(1, 40) if not torch.equal(outs[it], outs[0])]
+    assert not bad, bad[:10]
+    ref_b = torch.empty_like(yb)
+    Fn.conv2d_fused(desc, xb, wb, scale, shift, alpha, None, out=ref_b)
+    torch.cuda.synchronize()
+    assert torch.equal(yb, ref_b)
+
+
 def _cinp_check(N, H, W, case, check_ref=True):
     Cin, Cout = case["Cin"], case["Cout"]
     act, act_param, alpha_pc = case.get("act", L.ACT_NONE), case.get("act_param", 0.0), case.get("alpha_pc", 0)
